@@ -1,0 +1,82 @@
+"""Oracle: exact multi-output GP posterior (numpy, float64).  TEST INFRASTRUCTURE - see oracle/__init__.py.
+
+Restates what the reference asks gpytorch 0.3.2 to compute (PARITY UNPINNED on values: gpytorch is not available):
+
+* model: ``n_s`` independent exact GPs on shared inputs, zero mean, ``ScaleKernel(RBFKernel(ard))``, Gaussian
+  likelihood -- reference ``safe_exploration/ssm_cem/gp_ssm_cem.py:33-57`` and
+  ``safe_exploration/ssm_pytorch/gaussian_process.py:71-79,136-140``;
+* prediction INCLUDES the likelihood noise (``self._likelihood(self._model(z))``, ``gp_ssm_cem.py:89-94``);
+* Jacobian of the mean w.r.t. the stacked input ``z=(x,u)`` laid out ``[N x n_s x (n_s+n_u)]``
+  (``gp_ssm_cem.py:59-73``, ``ssm_pytorch/utilities.py:54-85`` get it from autograd; here it is analytic).
+"""
+import numpy as np
+import scipy.linalg as sla
+
+
+class ExactGP:
+    """Hyper-parameters are explicit inputs; nothing is learned here.
+
+    lengthscale [n_s x D], outputscale [n_s], noise [n_s]; X [N x D]; Y [N x n_s].
+    """
+
+    def __init__(self, X, Y, lengthscale, outputscale, noise):
+        self.X = np.asarray(X, dtype=np.float64)
+        self.Y = np.asarray(Y, dtype=np.float64)
+        self.n, self.D = self.X.shape
+        self.n_s = self.Y.shape[1]
+        self.ls = np.broadcast_to(np.asarray(lengthscale, dtype=np.float64), (self.n_s, self.D)).copy()
+        self.s = np.broadcast_to(np.asarray(outputscale, dtype=np.float64), (self.n_s,)).copy()
+        self.noise = np.broadcast_to(np.asarray(noise, dtype=np.float64), (self.n_s,)).copy()
+        self.L = []      # lower Cholesky factors of K_d + noise_d I
+        self.alpha = []  # (K_d + noise_d I)^-1 y_d
+        for d in range(self.n_s):
+            K = self.kernel(d, self.X, self.X) + self.noise[d] * np.eye(self.n)
+            L = np.linalg.cholesky(K)
+            self.L.append(L)
+            self.alpha.append(sla.cho_solve((L, True), self.Y[:, d]))
+
+    def kernel(self, d, A, B):
+        """k_d(a,b) = s_d exp(-1/2 sum_j ((a_j-b_j)/l_dj)^2)   [len(A) x len(B)]"""
+        a = A / self.ls[d]
+        b = B / self.ls[d]
+        out = np.empty((a.shape[0], b.shape[0]))
+        step = max(1, 2_000_000 // max(1, b.shape[0] * self.D))
+        for i in range(0, a.shape[0], step):  # direct differences: no cancellation from the expanded square
+            diff = a[i:i + step, None, :] - b[None, :, :]
+            out[i:i + step] = (diff * diff).sum(2)
+        return self.s[d] * np.exp(-0.5 * out)
+
+    def predict(self, z, jacobians=True):
+        """z [P x D] -> mean [P x n_s], var [P x n_s] (noise included), jac [P x n_s x D] or None."""
+        z = np.asarray(z, dtype=np.float64)
+        P = z.shape[0]
+        mean = np.empty((P, self.n_s))
+        var = np.empty((P, self.n_s))
+        jac = np.empty((P, self.n_s, self.D)) if jacobians else None
+        for d in range(self.n_s):
+            ks = self.kernel(d, z, self.X)                     # [P x N]
+            mean[:, d] = ks @ self.alpha[d]
+            v = sla.solve_triangular(self.L[d], ks.T, lower=True)  # L^-1 k*   [N x P]
+            var[:, d] = self.s[d] - (v * v).sum(0) + self.noise[d]
+            if jacobians:
+                w = ks * self.alpha[d][None, :]               # [P x N]
+                # d mean_d / d z_j = sum_i alpha_i k_i (X_ij - z_j) / l_dj^2
+                jac[:, d, :] = (w @ self.X - w.sum(1)[:, None] * z) / (self.ls[d] ** 2)[None, :]
+        return mean, var, jac
+
+    # the operands the HIP kernels consume (checked against the device-side fit in tests)
+    def linv(self):
+        """[n_s x N x N] inverse Cholesky factors W_d = L_d^-1 (lower triangular)."""
+        eye = np.eye(self.n)
+        return np.stack([sla.solve_triangular(self.L[d], eye, lower=True) for d in range(self.n_s)])
+
+
+def synthetic_training_set(n, n_s, n_u, seed=0, scale=0.5):
+    """Seeded synthetic training set of SURVEY 8(d): X ~ U(-scale, scale), y = f(X) + noise (- linear prior)."""
+    rng = np.random.default_rng(seed)
+    D = n_s + n_u
+    X = rng.uniform(-scale, scale, size=(n, D))
+    Wm = rng.normal(size=(D, n_s)) * 0.3
+    # targets play the role of "error to the linear prior" (reference safempc_cem.py:314-327 subtracts it)
+    Y = np.sin(X @ Wm) * 0.2 + 0.05 * np.cos(3.0 * X[:, :n_s]) + rng.normal(size=(n, n_s)) * 0.01
+    return X, Y

@@ -1,0 +1,163 @@
+"""CPU: the numpy oracle reproduces what the REFERENCE computed (tests/golden/*.npz, made by make_golden.py).
+
+Tolerances: the reference's own parity tests use np.allclose defaults (rtol 1e-5, atol 1e-8,
+test_gp_reachability_pytorch.py:133-136); the oracle is held to rtol 1e-10 / atol 1e-13.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cem, reachability as reach
+from oracle.gp import ExactGP
+
+RTOL, ATOL = 1e-10, 1e-13
+CASES = ['onestep_pendulum_lin', 'onestep_pendulum_nolin', 'onestep_pendulum_env', 'onestep_cartpole_lin',
+         'onestep_cartpole_nolin']
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + '.npz')))
+
+
+def gp_of(g):
+    return ExactGP(g['X'], g['Y'], g['ls'], g['s'], g['noise'])
+
+
+def lin(g):
+    return (g['a'], g['b']) if bool(g['has_lin']) else (None, None)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_onestep_point_branch(golden_dir, name):
+    g = load(golden_dir, name)
+    a, b = lin(g)
+    p1, q1, sig, _ = reach.onestep_reachability(g['p'], gp_of(g), g['k_ff'], g['l_mu'], g['l_sigma'], None, g['k_fb'],
+                                                float(g['c_safety']), a=a, b=b)
+    np.testing.assert_allclose(p1, g['point_p'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(q1, g['point_q'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(sig, g['point_sigma'], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_onestep_ellipsoid_branch(golden_dir, name):
+    g = load(golden_dir, name)
+    a, b = lin(g)
+    p1, q1, sig, _ = reach.onestep_reachability(g['p'], gp_of(g), g['k_ff'], g['l_mu'], g['l_sigma'], g['q'],
+                                                g['k_fb'], float(g['c_safety']), a=a, b=b)
+    np.testing.assert_allclose(p1, g['ell_p'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(q1, g['ell_q'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(sig, g['ell_sigma'], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_chained_rollout(golden_dir, name):
+    g = load(golden_dir, name)
+    n_s = g['p'].shape[1]
+    n_u = g['k_ff'].shape[1]
+    a, b = lin(g)
+    if a is None:
+        a, b = np.eye(n_s), np.zeros((n_s, n_u))
+    prob = cem.Problem(n_s, n_u, a, b, g['k_fb'], g['l_mu'], g['l_sigma'], float(g['c_safety']),
+                       np.eye(n_s), np.ones((n_s, 1)), -np.ones(n_u), np.ones(n_u))
+    res = cem.rollout(prob, gp_of(g), g['p'], g['actions'])
+    np.testing.assert_allclose(res.traj_p, g['chain_p'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.traj_q, g['chain_q'], rtol=1e-9, atol=ATOL)
+    np.testing.assert_allclose(res.sigma, g['chain_sigma'], rtol=RTOL, atol=ATOL)
+
+
+def test_polytope_tables(golden_dir):
+    g = load(golden_dir, 'polytope')
+    d = reach.lin_ellipsoid_safety_distance(g['p'], g['q'], g['box_A'], g['box_b'])
+    np.testing.assert_allclose(d, g['dist'], rtol=RTOL, atol=ATOL)
+    # known answers of test_gp_reachability_pytorch.py:183-219: inside / partially out / outside
+    ins = reach.is_ellipsoid_inside_polytope(g['p3'], g['q3'], g['box_A'], g['box_b'])
+    assert list(ins) == [True, False, False] == list(g['inside'])
+    d = reach.lin_ellipsoid_safety_distance(g['pr'], g['qr'], g['hr'], g['hv'])
+    np.testing.assert_allclose(d, g['dist_r'], rtol=RTOL, atol=ATOL)
+    assert (reach.is_ellipsoid_inside_polytope(g['pr'], g['qr'], g['hr'], g['hv']) == g['inside_r']).all()
+
+
+@pytest.mark.parametrize('tag', ['21', '41', '42'])
+def test_helper_tables(golden_dir, tag):
+    g = load(golden_dir, 'helpers')
+    um, us = reach.compute_remainder_overapproximations(g[f'rem_q_{tag}'], g[f'rem_kfb_{tag}'], g[f'rem_lmu_{tag}'],
+                                                        g[f'rem_lsg_{tag}'])
+    np.testing.assert_allclose(um, g[f'rem_umu_{tag}'], rtol=1e-9, atol=ATOL)
+    np.testing.assert_allclose(us, g[f'rem_usig_{tag}'], rtol=1e-9, atol=ATOL)
+    ps, qs = reach.sum_two_ellipsoids(g[f'sum_p1_{tag}'], g[f'sum_q1_{tag}'], g[f'sum_p2_{tag}'], g[f'sum_q2_{tag}'])
+    np.testing.assert_allclose(ps, g[f'sum_p_{tag}'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(qs, g[f'sum_q_{tag}'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(reach.ellipsoid_from_rectangle(g[f'rect_ub_{tag}']), g[f'rect_q_{tag}'], rtol=RTOL,
+                               atol=ATOL)
+
+
+def test_fix_zeros_nans_semantics():
+    # gp_reachability_pytorch.py:234-243
+    x, ok, z = reach.fix_zeros_nans(np.array([[1.0, np.nan]]))
+    assert not ok
+    x, ok, z = reach.fix_zeros_nans(np.array([[1.0, 0.0, -2.0]]))
+    assert ok and z and list(x[0]) == [1.0, 1e-5, 1e-5]
+    x, ok, z = reach.fix_zeros_nans(np.array([[1.0, -2.0]]))  # negatives survive when no exact zero is present
+    assert ok and not z and list(x[0]) == [1.0, -2.0]
+
+
+def test_pq_flatten_roundtrip():
+    # test_safempc_cem.py:23-42
+    p = np.array([[1., 2.], [3., 4.]])
+    q = np.arange(8, dtype=float).reshape(2, 2, 2) + 1
+    flat = reach.pq_flatten(p, q)
+    assert flat.shape == (2, 6) and list(flat[0]) == [1, 2, 1, 2, 3, 4]
+    p2, q2 = reach.pq_unflatten(flat, 2)
+    assert (p2 == p).all() and (q2 == q).all()
+    p3, q3 = reach.pq_unflatten(reach.pq_flatten(p, None), 2)
+    assert q3 is None and (p3 == p).all()
+
+
+def test_gp_structure():
+    """No test of the reference pins gpytorch's values; these pin the structure:
+    independent outputs on shared inputs, likelihood noise included, interpolation, analytic == numeric Jacobian."""
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (30, 3))
+    Y = np.stack([np.sin(X.sum(1)), np.cos(X[:, 0])], 1)
+    ls = np.array([[0.8, 1.0, 1.2], [0.5, 0.9, 2.0]])
+    gp = ExactGP(X, Y, ls, [0.7, 1.1], [1e-6, 1e-6])
+    z = rng.uniform(-1, 1, (7, 3))
+    m, v, j = gp.predict(z)
+    for d in range(2):  # batch GP == independent single-output GPs (test_gaussian_process.py:108-164)
+        g1 = ExactGP(X, Y[:, d:d + 1], ls[d:d + 1], [gp.s[d]], [gp.noise[d]])
+        m1, v1, j1 = g1.predict(z)
+        np.testing.assert_allclose(m[:, d], m1[:, 0], rtol=1e-12)
+        np.testing.assert_allclose(v[:, d], v1[:, 0], rtol=1e-12)
+        np.testing.assert_allclose(j[:, d], j1[:, 0], rtol=1e-12)
+    mt, vt, _ = gp.predict(X, False)  # near-noiseless GP interpolates; variance at data ~ 2 x noise
+    np.testing.assert_allclose(mt, Y, atol=1e-4)
+    assert (vt < 1e-4).all() and (vt > 0).all()
+    eps = 1e-6
+    for c in range(3):  # Jacobian layout [P x n_s x D] (test_utilities.py:71-105)
+        dz = np.zeros(3); dz[c] = eps
+        mp, _, _ = gp.predict(z + dz, False)
+        mm, _, _ = gp.predict(z - dz, False)
+        np.testing.assert_allclose(j[:, :, c], (mp - mm) / (2 * eps), rtol=1e-5, atol=1e-8)
+
+
+def test_action_constraint_known_answer():
+    # test_safempc_cem.py:59-71: u in [-4, 4], actions 0.2, -5, 6 -> penalty 2 * 3
+    n_s, n_u = 2, 1
+    X = np.random.default_rng(1).uniform(-1, 1, (10, 3))
+    gp = ExactGP(X, np.zeros((10, 2)), 1.0, 1.0, 0.1)
+    prob = cem.Problem(n_s, n_u, np.eye(2), np.zeros((2, 1)), np.zeros((1, 2)), np.full(2, .01), np.full(2, .01), 1.0,
+                       np.eye(2), np.full((2, 1), 1e9), np.array([-4.]), np.array([4.]))
+    res = cem.rollout(prob, gp, np.zeros(2), np.array([[[0.2], [-5.], [6.]]]))
+    assert res.con_cost[0] == 2 * 3
+
+
+def test_rank_and_refit():
+    con = np.array([0., 10., 0., 3., 0.])
+    obj = np.array([5., -100., 1., -50., 1.])
+    assert list(cem.rank(con, obj, 3)) == [2, 4, 0]          # feasible first, by objective, ties by index
+    assert list(cem.rank(con, obj, 5)) == [2, 4, 0, 3, 1]    # then by constraint cost
+    acts = np.arange(12, dtype=float).reshape(3, 2, 2)
+    m, s = cem.refit(acts)
+    np.testing.assert_allclose(m, acts.mean(0))
+    np.testing.assert_allclose(s, acts.std(0, ddof=1))

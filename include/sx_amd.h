@@ -1,0 +1,159 @@
+/*
+ * sx_amd.h -- C ABI of libsxamd.so, the MI355X (gfx950) implementation of the CEM safe-MPC hot path of
+ * oscarkey/safe-exploration.
+ *
+ * The reference has no FFI: its boundary is two Python ABCs and one factory branch.  This header is
+ * the boundary a maintainer binds with ctypes (INTEGRATION.md shows the stub).  Each entry point names the reference
+ * interface it replaces; paths are relative to the reference root.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device pointer into HBM, row-major, contiguous, float64 unless noted;
+ *     the library borrows it for the duration of the call's kernels and allocates nothing persistent;
+ *   - structs are passed by pointer to HOST memory and copied into kernel arguments;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued on it, nothing is
+ *     synchronised, the calls are re-entrant per stream;
+ *   - return value: SX_OK or an SX_ERR_* code (bad shape, unsupported dimension, HIP launch error);
+ *   - numerical trouble is reported through a device status word (SX_STATUS_* bits), read by the host once per solve
+ *     and mapped onto the reference's ValueError (safe_exploration/gp_reachability_pytorch.py:76-80,117-121,149-153).
+ */
+#ifndef SX_AMD_H
+#define SX_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SX_MAX_NS 4              /* state dimension: pendulum 2, cart-pole 4 */
+#define SX_MAX_NU 2
+#define SX_MAX_D (SX_MAX_NS + SX_MAX_NU)
+#define SX_MAX_M 16              /* polytope rows: pendulum 4, cart-pole 9 */
+#define SX_TILE 16               /* particles per workgroup = one f64 MFMA tile column block */
+
+#define SX_OK 0
+#define SX_ERR_ARG 1             /* null pointer / non-positive size / inconsistent shapes */
+#define SX_ERR_UNSUPPORTED 2     /* (n_s, n_u) not instantiated, m > SX_MAX_M, n_train too large for the fused path */
+#define SX_ERR_LAUNCH 3          /* HIP reported an error on launch */
+
+#define SX_STATUS_NAN 1          /* _fix_zeros_nans saw a NaN: gp_reachability_pytorch.py:234-236 */
+#define SX_STATUS_ZERO_FIX 2     /* an exact zero was replaced by 1e-5: gp_reachability_pytorch.py:238-241 */
+#define SX_STATUS_UB_NONPOS 4    /* ellipsoid_from_rectangle got u_b <= 0: utils_ellipsoid.py:304 */
+
+#define SX_OBJ_NEG_VARIANCE 0    /* -sum_d sigma_d: safempc_cem.py:308-311 */
+#define SX_OBJ_AFFINE_ABS 1      /* sum_j w_abs_j |target_j - p_j| + w_lin_j p_j: environments.py:505-510, lunarlander.py:111-113 */
+#define SX_CON_TERMINAL 0        /* EllipsoidTerminalConstraint: safempc_cem.py:102-113 */
+#define SX_CON_ALL_STATES 1      /* EllipsoidStateConstraint on every prefix: safempc_cem.py:116-132 */
+
+#define SX_ACTION_VIOLATION_COST 3.0  /* test_safempc_cem.py:59-71 */
+#define SX_STATE_VIOLATION_COST 10.0  /* safempc_cem.py:132 */
+
+/* Exact multi-output GP in the form the kernels consume.
+ * Replaces: the gpytorch model behind GpCemSSM (ssm_cem/gp_ssm_cem.py:33-57, ssm_pytorch/gaussian_process.py:82-140).
+ * Built by sx_gp_pack() from the inverse Cholesky factors W_d = chol(K_d + noise_d I)^-1 and alpha_d. */
+typedef struct sx_gp_model {
+    int32_t n_s, n_u;            /* outputs, action dims; D = n_s + n_u inputs */
+    int32_t n_train;             /* N */
+    int32_t n_pad;               /* 16 * ceil(N / 16) */
+    double inv_ls2[SX_MAX_NS * SX_MAX_D];  /* [n_s x D] 1 / lengthscale^2 (ARD, per output) */
+    double outputscale[SX_MAX_NS];
+    double noise[SX_MAX_NS];     /* likelihood noise, added to the predictive variance (gp_ssm_cem.py:93) */
+    const double* x_train;       /* dev [N x D] */
+    const double* w_pack;        /* dev, sx_gp_pack_sizes() doubles: W_d in MFMA fragment order */
+    const double* r_pack;        /* dev: rows alpha_d, alpha_d * X_j / l_dj^2 in MFMA fragment order */
+} sx_gp_model;
+
+/* Environment / solver constants of one MPC problem.
+ * Replaces: the attributes CemSafeMPC reads from env/conf (safempc_cem.py:166-196) and the constraint objects
+ * (safempc_cem.py:135-146). */
+typedef struct sx_env {
+    int32_t n_s, n_u;
+    int32_t m;                   /* polytope rows */
+    int32_t obj_mode;            /* SX_OBJ_* */
+    int32_t con_mode;            /* SX_CON_* */
+    int32_t reserved;
+    double beta;                 /* c_safety */
+    double a[SX_MAX_NS * SX_MAX_NS];      /* linear prior A (zeros if no prior: safempc_cem.py:291-296) */
+    double b[SX_MAX_NS * SX_MAX_NU];
+    double k_fb[SX_MAX_NU * SX_MAX_NS];   /* LQR feedback (safempc_simple.py:1105-1129) */
+    double l_mu[SX_MAX_NS];
+    double l_sigma[SX_MAX_NS];
+    double h_mat[SX_MAX_M * SX_MAX_NS];   /* safe polytope h_mat x <= h_vec */
+    double h_vec[SX_MAX_M];
+    double u_min[SX_MAX_NU];
+    double u_max[SX_MAX_NU];
+    double obj_w_abs[SX_MAX_NS];
+    double obj_target[SX_MAX_NS];
+    double obj_w_lin[SX_MAX_NS];
+} sx_env;
+
+/* Library / build identification: returns "sxamd <version> gfx950". */
+const char* sx_version(void);
+
+/* Doubles needed for sx_gp_model.w_pack / r_pack. */
+int sx_gp_pack_sizes(int n_s, int n_train, int64_t* w_doubles, int64_t* r_doubles);
+
+/* Lays W_d = L_d^-1 (dev [n_s x N x N], lower triangular) and alpha (dev [n_s x N]) out in fragment order.
+ * model->{n_s,n_u,n_train,inv_ls2,x_train,w_pack,r_pack} must be set; n_pad is filled in.
+ * Replaces: GpCemSSM._update_model (ssm_cem/gp_ssm_cem.py:96-101) -- where the prediction operands are (re)built. */
+int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void* stream);
+
+/* Posterior at z dev [P x D]: mean dev [P x n_s], var dev [P x n_s] (noise included), jac dev [P x n_s x D] or NULL.
+ * Replaces: GpCemSSM.predict_with_jacobians / predict_without_jacobians / _predict (ssm_cem/gp_ssm_cem.py:59-94)
+ * and compute_jacobian_fast (ssm_pytorch/utilities.py:54-85). */
+int sx_gp_predict(const sx_gp_model* model, const double* z, int P, double* mean, double* var, double* jac,
+                  void* stream);
+
+/* One-step ellipsoidal reachability given the GP outputs at (p, u).
+ * p dev [P x n_s]; Q dev [P x n_s x n_s] or NULL (point branch); u dev [P x n_u]; mean/var dev [P x n_s];
+ * jac dev [P x n_s x D] (ignored in the point branch); outputs p1 dev [P x n_s], Q1 dev [P x n_s x n_s],
+ * sigma dev [P x n_s] (the variance after the zero fix-up); status dev int32 (OR-ed).
+ * Uses env->{a,b,k_fb,l_mu,l_sigma,beta}.
+ * Replaces: onestep_reachability (gp_reachability_pytorch.py:18-181) with its helpers
+ * compute_remainder_overapproximations_pytorch (utils.py:152-194), ellipsoid_from_rectangle_pytorch and
+ * sum_two_ellipsoids_pytorch (utils_ellipsoid.py:102-140,282-309), _fix_zeros_nans (:234-243). */
+int sx_onestep_reach(const sx_env* env, int P, const double* p, const double* Q, const double* u, const double* mean,
+                     const double* var, const double* jac, double* p1, double* Q1, double* sigma, int32_t* status,
+                     void* stream);
+
+/* d dev [P x m] = h_mat p + c_safety sqrt(diag(h_mat Q h_mat^T)) - h_vec; inside dev uint8 [P] or NULL.
+ * Replaces: lin_ellipsoid_safety_distance / is_ellipsoid_inside_polytope (gp_reachability_pytorch.py:184-231). */
+int sx_polytope_distance(const sx_env* env, int P, const double* p, const double* Q, double c_safety, double* d,
+                         uint8_t* inside, void* stream);
+
+/* The fused CEM particle rollout: E independent problems x P particles x H steps in ONE launch.
+ *   x0      dev [E x n_s]              start states (points; the reference starts every solve from a point,
+ *                                      safempc_cem.py:234-235)
+ *   q0      dev [E x n_s x n_s] | NULL start shape matrices (NULL = point)
+ *   mean,std dev [E x H x n_u]         sampling distribution (ignored when noise == NULL)
+ *   noise   dev [E x P x H x n_u]|NULL standard-normal draws; NULL = `actions` is an INPUT
+ *   actions dev [E x P x H x n_u]      out: mean + std * noise  (or in, see above)
+ *   traj    dev [E x P x H x (n_s + n_s^2)] | NULL   flat states [p | vec_rowmajor(Q)] (PQFlattener, safempc_cem.py:30-76)
+ *   sigma   dev [E x P x H x n_s] | NULL
+ *   obj_cost, con_cost dev [E x P]     summed objective / constraint cost
+ *   status  dev int32                  OR of SX_STATUS_*
+ * Replaces: the H sequential DynamicsFunc callbacks + per-trajectory Constraint calls the optimiser makes per
+ * iteration (safempc_cem.py:102-156,288-312; call sites of the absent constrained-cem-mpc). */
+int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
+                   const double* mean, const double* std, const double* noise, double* actions, double* traj,
+                   double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream);
+
+/* Ranking + elite refit for E problems, one workgroup each.
+ * Candidates c = 0..P-1 of problem e have con = con_cost[(e*P+c)*cost_stride], obj likewise, and an action row of
+ * `row_len` doubles at actions + (e*P+c)*act_stride.  Order: lexicographic (con, obj, c); NaN sorts last.
+ *   elite_idx  dev int32 [E x k]            sorted elite indices (may be NULL)
+ *   elite_rows dev [E x k x (2 + row_len)]  [con, obj, actions...] of the elites, sorted (may be NULL) -- the buffer
+ *                                           that is all-reduced across GPUs
+ *   mean, std  dev [E x row_len]            refit (unbiased std; 0 when k == 1)  (may be NULL: no refit)
+ *   best       dev [E x row_len]            first-ranked action sequence (may be NULL)
+ *   best_ok    dev int32 [E]                1 if the first-ranked candidate has con == 0 (may be NULL)
+ * Replaces: elite selection / refit / "best feasible or None" of ConstrainedCemMpc.get_actions (safempc_cem.py:235,
+ * test_safempc_cem.py:83-148). */
+int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, const double* obj_cost,
+                      int64_t cost_stride, const double* actions, int64_t act_stride, int32_t* elite_idx,
+                      double* elite_rows, double* mean, double* std, double* best, int32_t* best_ok, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SX_AMD_H */

@@ -69,14 +69,3 @@ class ExactGP:
         """[n_s x N x N] inverse Cholesky factors W_d = L_d^-1 (lower triangular)."""
         eye = np.eye(self.n)
         return np.stack([sla.solve_triangular(self.L[d], eye, lower=True) for d in range(self.n_s)])
-
-
-def synthetic_training_set(n, n_s, n_u, seed=0, scale=0.5):
-    """Seeded synthetic training set of SURVEY 8(d): X ~ U(-scale, scale), y = f(X) + noise (- linear prior)."""
-    rng = np.random.default_rng(seed)
-    D = n_s + n_u
-    X = rng.uniform(-scale, scale, size=(n, D))
-    Wm = rng.normal(size=(D, n_s)) * 0.3
-    # targets play the role of "error to the linear prior" (reference safempc_cem.py:314-327 subtracts it)
-    Y = np.sin(X @ Wm) * 0.2 + 0.05 * np.cos(3.0 * X[:, :n_s]) + rng.normal(size=(n, n_s)) * 0.01
-    return X, Y

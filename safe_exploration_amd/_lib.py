@@ -1,0 +1,109 @@
+"""ctypes binding of libsxamd.so (include/sx_amd.h).  There is no CPU fallback: a missing library is an error."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+import numpy as np
+import torch
+
+SX_MAX_NS = 4
+SX_MAX_NU = 2
+SX_MAX_D = SX_MAX_NS + SX_MAX_NU
+SX_MAX_M = 16
+SX_TILE = 16
+
+SX_OK, SX_ERR_ARG, SX_ERR_UNSUPPORTED, SX_ERR_LAUNCH = 0, 1, 2, 3
+SX_STATUS_NAN, SX_STATUS_ZERO_FIX, SX_STATUS_UB_NONPOS = 1, 2, 4
+SX_OBJ_NEG_VARIANCE, SX_OBJ_AFFINE_ABS = 0, 1
+SX_CON_TERMINAL, SX_CON_ALL_STATES = 0, 1
+
+_ERR = {SX_ERR_ARG: 'bad argument (null pointer, non-positive size or inconsistent shapes)',
+        SX_ERR_UNSUPPORTED: 'unsupported dimension (n_s/n_u not instantiated, too many polytope rows, or the training '
+                            'set does not fit the fused kernel\'s LDS budget)',
+        SX_ERR_LAUNCH: 'HIP launch error'}
+
+
+class SxGpModel(Structure):
+    _fields_ = [('n_s', c_int32), ('n_u', c_int32), ('n_train', c_int32), ('n_pad', c_int32),
+                ('inv_ls2', c_double * (SX_MAX_NS * SX_MAX_D)), ('outputscale', c_double * SX_MAX_NS),
+                ('noise', c_double * SX_MAX_NS), ('x_train', c_void_p), ('w_pack', c_void_p), ('r_pack', c_void_p)]
+
+
+class SxEnv(Structure):
+    _fields_ = [('n_s', c_int32), ('n_u', c_int32), ('m', c_int32), ('obj_mode', c_int32), ('con_mode', c_int32),
+                ('reserved', c_int32), ('beta', c_double),
+                ('a', c_double * (SX_MAX_NS * SX_MAX_NS)), ('b', c_double * (SX_MAX_NS * SX_MAX_NU)),
+                ('k_fb', c_double * (SX_MAX_NU * SX_MAX_NS)), ('l_mu', c_double * SX_MAX_NS),
+                ('l_sigma', c_double * SX_MAX_NS), ('h_mat', c_double * (SX_MAX_M * SX_MAX_NS)),
+                ('h_vec', c_double * SX_MAX_M), ('u_min', c_double * SX_MAX_NU), ('u_max', c_double * SX_MAX_NU),
+                ('obj_w_abs', c_double * SX_MAX_NS), ('obj_target', c_double * SX_MAX_NS),
+                ('obj_w_lin', c_double * SX_MAX_NS)]
+
+
+# name -> (restype, argtypes): exactly the entry points include/sx_amd.h declares
+SIGNATURES = {
+    'sx_version': (c_char_p, []),
+    'sx_gp_pack_sizes': (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    'sx_gp_pack': (c_int, [POINTER(SxGpModel), c_void_p, c_void_p, c_void_p]),
+    'sx_gp_predict': (c_int, [POINTER(SxGpModel), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'sx_onestep_reach': (c_int, [POINTER(SxEnv), c_int] + [c_void_p] * 11),
+    'sx_polytope_distance': (c_int, [POINTER(SxEnv), c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p,
+                                     c_void_p]),
+    'sx_cem_rollout': (c_int, [POINTER(SxGpModel), POINTER(SxEnv), c_int, c_int, c_int] + [c_void_p] * 12),
+    'sx_cem_rank_refit': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64]
+                          + [c_void_p] * 7),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libsxamd.so')
+_lib = None
+
+
+class SxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libsxamd.so once.  Raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SxError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          f'(safe_exploration_amd has no CPU fallback)')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != SX_OK:
+        raise SxError(f'{what}: {_ERR.get(code, code)}')
+
+
+def ptr(t):
+    """Device pointer of a contiguous float64/int tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'libsxamd takes contiguous row-major buffers'
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(t, name: str):
+    if not t.is_cuda:
+        raise SxError(f'{name} must live on the GPU: safe_exploration_amd has no CPU path (got device {t.device})')
+    if t.dtype != torch.float64:
+        raise SxError(f'{name} must be float64 (the reference runs in double precision), got {t.dtype}')
+
+
+def fill(carray, values) -> None:
+    flat = np.asarray(values, dtype=np.float64).reshape(-1)
+    assert len(flat) <= len(carray), (len(flat), len(carray))
+    for i, v in enumerate(flat):
+        carray[i] = float(v)

@@ -1,0 +1,823 @@
+// libsxamd: kernels + C ABI (include/sx_amd.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/sx_amd.h"
+#include "sx_gp.hpp"
+#include "sx_reach.hpp"
+
+namespace sx {
+
+constexpr int kRolloutThreads = 256;  // 4 waves: one per SIMD of the CU that owns the 16-particle tile
+constexpr int kPredictThreads = 256;
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_pack: W_d / alpha_d -> fragment order
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pack_w_kernel(const double* __restrict__ linv, int n_s, int n, int n_pad, double* __restrict__ w_pack) {
+    const int nrb = n_pad >> 4;
+    const int64_t wpo = w_pairs_per_output(nrb);
+    const int64_t total = (int64_t)n_s * wpo * 128;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i & 1);
+        const int lane = (int)((i >> 1) & 63);
+        int64_t pair = i >> 7;
+        const int d = (int)(pair / wpo);
+        pair -= (int64_t)d * wpo;
+        // row-block rb owns pairs [rb (rb + 1), (rb + 1)(rb + 2))
+        int rb = (int)((sqrt(4.0 * (double)pair + 1.0) - 1.0) * 0.5);
+        while ((int64_t)rb * (rb + 1) > pair) --rb;
+        while ((int64_t)(rb + 1) * (rb + 2) <= pair) ++rb;
+        const int q = (int)(pair - (int64_t)rb * (rb + 1));
+        const int row = rb * 16 + (lane & 15);
+        const int k = 8 * q + 4 * slot + (lane >> 4);
+        double v = 0.0;
+        if (row < n && k <= row) v = linv[((int64_t)d * n + row) * n + k];
+        w_pack[i] = v;
+    }
+}
+
+template <int MAXNS, int MAXD>
+struct PackRArgs {
+    double inv_ls2[MAXNS * MAXD];
+};
+
+__global__ void pack_r_kernel(const double* __restrict__ alpha, const double* __restrict__ x_train,
+                              PackRArgs<SX_MAX_NS, SX_MAX_D> args, int n_s, int D, int n, int n_pad,
+                              double* __restrict__ r_pack) {
+    const int ppo = n_pad >> 3;  // pairs per output
+    const int64_t total = (int64_t)n_s * ppo * 128;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i & 1);
+        const int lane = (int)((i >> 1) & 63);
+        int64_t pair = i >> 7;
+        const int d = (int)(pair / ppo);
+        const int q = (int)(pair - (int64_t)d * ppo);
+        const int row = lane & 15;
+        const int k = 8 * q + 4 * slot + (lane >> 4);
+        double v = 0.0;
+        if (k < n) {
+            const double al = alpha[(int64_t)d * n + k];
+            if (row == 0)
+                v = al;
+            else if (row <= D)
+                v = al * x_train[(int64_t)k * D + row - 1] * args.inv_ls2[d * D + row - 1];
+        }
+        r_pack[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_predict: one 16-point tile per workgroup
+// ---------------------------------------------------------------------------------------------------------------
+template <int NS, int NU>
+__global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS, NS + NU> gc, const double* __restrict__ z,
+                                                                     int P, double* __restrict__ mean,
+                                                                     double* __restrict__ var, double* __restrict__ jac) {
+    constexpr int D = NS + NU;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    GpTileLds<NS, D> lds;
+    const int nw = blockDim.x >> 6;
+    lds.carve(smem, gc.n_train, gc.n_pad, nw);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    gp_load_xs(gc, lds);
+    for (int tile = blockIdx.x; tile * SX_TILE < P; tile += gridDim.x) {
+        const int g0 = tile * SX_TILE;
+        if (tid < SX_TILE * D) {
+            const int c = tid / D, j = tid - c * D;
+            lds.zs[tid] = (g0 + c < P) ? z[(int64_t)(g0 + c) * D + j] : 0.0;
+        }
+        __syncthreads();
+        gp_kstar_phase(gc, lds);
+        __syncthreads();
+        gp_mfma_phase(gc, lds, wave, nw, lane);
+        __syncthreads();
+        if (tid < SX_TILE && g0 + tid < P) {
+            double zz[D], m[NS], v[NS], jc[NS][D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) zz[j] = lds.zs[tid * D + j];
+            if (jac) {
+                gp_collect<NS, D, true>(gc, lds, nw, tid, zz, m, v, jc);
+            } else {
+                gp_collect<NS, D, false>(gc, lds, nw, tid, zz, m, v, jc);
+            }
+            const int64_t g = g0 + tid;
+#pragma unroll
+            for (int d = 0; d < NS; ++d) {
+                mean[g * NS + d] = m[d];
+                var[g * NS + d] = v[d];
+                if (jac) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) jac[(g * NS + d) * D + j] = jc[d][j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_onestep_reach / sx_polytope_distance: one particle per lane
+// ---------------------------------------------------------------------------------------------------------------
+template <int NS, int NU>
+__global__ void onestep_reach_kernel(ReachConst<NS, NU> rc, int P, const double* __restrict__ p_in,
+                                     const double* __restrict__ q_in, const double* __restrict__ u_in,
+                                     const double* __restrict__ mean_in, const double* __restrict__ var_in,
+                                     const double* __restrict__ jac_in, double* __restrict__ p_out,
+                                     double* __restrict__ q_out, double* __restrict__ sig_out, int* __restrict__ status) {
+    constexpr int D = NS + NU;
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    double p[NS], u[NU], mean[NS], var[NS], p1[NS], Q1[NS][NS];
+    int st = 0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        p[i] = p_in[g * NS + i];
+        mean[i] = mean_in[g * NS + i];
+        var[i] = var_in[g * NS + i];
+    }
+#pragma unroll
+    for (int c = 0; c < NU; ++c) u[c] = u_in[g * NU + c];
+    if (q_in == nullptr) {
+        reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st);
+    } else {
+        double Q[NS][NS], jac[NS][D];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) Q[i][j] = q_in[(g * NS + i) * NS + j];
+#pragma unroll
+            for (int j = 0; j < D; ++j) jac[i][j] = jac_in[(g * NS + i) * D + j];
+        }
+        reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        p_out[g * NS + i] = p1[i];
+        sig_out[g * NS + i] = var[i];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) q_out[(g * NS + i) * NS + j] = Q1[i][j];
+    }
+    if (st) atomicOr(status, st);
+}
+
+template <int NS>
+struct PolyArgs {
+    double h_mat[SX_MAX_M * NS];
+    double h_vec[SX_MAX_M];
+    int m;
+};
+
+template <int NS>
+__global__ void polytope_kernel(PolyArgs<NS> pa, int P, double c_safety, const double* __restrict__ p_in,
+                                const double* __restrict__ q_in, double* __restrict__ d_out,
+                                uint8_t* __restrict__ inside) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    double p[NS], Q[NS][NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        p[i] = p_in[g * NS + i];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) Q[i][j] = q_in[(g * NS + i) * NS + j];
+    }
+    double d[SX_MAX_M];
+    const bool viol = polytope_violated<SX_MAX_M, NS>(pa.h_mat, pa.h_vec, pa.m, c_safety, p, Q, d);
+    for (int r = 0; r < pa.m; ++r) d_out[g * pa.m + r] = d[r];
+    if (inside) inside[g] = viol ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_cem_rollout: the fused H-step particle rollout.  One workgroup = 16 particles of one problem for all H steps.
+// ---------------------------------------------------------------------------------------------------------------
+struct RolloutPtrs {
+    const double* x0;
+    const double* q0;
+    const double* mean;
+    const double* std;
+    const double* noise;
+    double* actions;
+    double* traj;
+    double* sigma;
+    double* obj_cost;
+    double* con_cost;
+    int* status;
+    int E, P, H;
+};
+
+template <int NS, int NU>
+__global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc,
+                                                                      CostConst<SX_MAX_M, NS, NU> cc, RolloutPtrs rp) {
+    constexpr int D = NS + NU;
+    constexpr int S = NS + NS * NS;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    GpTileLds<NS, D> lds;
+    const int nw = blockDim.x >> 6;
+    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw);  // [16][H][NU]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int H = rp.H;
+    const int tiles_per_problem = (rp.P + SX_TILE - 1) / SX_TILE;
+    const int e = blockIdx.x / tiles_per_problem;
+    const int c0 = (blockIdx.x - e * tiles_per_problem) * SX_TILE;  // first particle of the tile within problem e
+
+    gp_load_xs(gc, lds);
+    // sample (or load) this tile's action sequences: a = mean + std * eps
+    for (int i = tid; i < SX_TILE * H * NU; i += blockDim.x) {
+        const int c = i / (H * NU);
+        const int r = i - c * (H * NU);
+        double a = 0.0;
+        if (c0 + c < rp.P) {
+            const int64_t gi = ((int64_t)e * rp.P + c0 + c) * (H * NU) + r;
+            if (rp.noise) {
+                a = rp.mean[(int64_t)e * H * NU + r] + rp.std[(int64_t)e * H * NU + r] * rp.noise[gi];
+                rp.actions[gi] = a;
+            } else {
+                a = rp.actions[gi];
+            }
+        }
+        acts[i] = a;
+    }
+    // per-particle state lives in the registers of thread c (tid < 16) for the whole rollout
+    const bool owner = tid < SX_TILE;
+    const bool valid = owner && (c0 + tid < rp.P);
+    double p[NS], Q[NS][NS];
+    bool have_q = rp.q0 != nullptr;
+    double obj = 0.0, con = 0.0;
+    int st = 0;
+    if (owner) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            p[i] = rp.x0[(int64_t)e * NS + i];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) Q[i][j] = have_q ? rp.q0[((int64_t)e * NS + i) * NS + j] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (owner) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = p[i];
+#pragma unroll
+        for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + 0) * NU + cidx];
+    }
+    __syncthreads();
+
+    for (int t = 0; t < H; ++t) {
+        gp_kstar_phase(gc, lds);
+        __syncthreads();
+        gp_mfma_phase(gc, lds, wave, nw, lane);
+        __syncthreads();
+        if (owner) {
+            double z[D], u[NU], mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
+#pragma unroll
+            for (int j = 0; j < D; ++j) z[j] = lds.zs[tid * D + j];
+#pragma unroll
+            for (int cidx = 0; cidx < NU; ++cidx) u[cidx] = z[NS + cidx];
+            int st_step = 0;
+            if (have_q) {
+                gp_collect<NS, D, true>(gc, lds, nw, tid, z, mean, var, jac);
+                reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st_step);
+            } else {
+                gp_collect<NS, D, false>(gc, lds, nw, tid, z, mean, var, jac);
+                reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st_step);
+            }
+            have_q = true;
+            if (valid) st |= st_step;
+            // costs (safempc_cem.py:102-132,304-312; action constraint: test_safempc_cem.py:59-71)
+            obj += objective_cost<SX_MAX_M, NS, NU>(cc, p1, var);
+            bool uviol = false;
+#pragma unroll
+            for (int cidx = 0; cidx < NU; ++cidx) uviol = uviol || (u[cidx] < cc.u_min[cidx]) || (u[cidx] > cc.u_max[cidx]);
+            if (uviol) con += SX_ACTION_VIOLATION_COST;
+            if (cc.con_mode == SX_CON_ALL_STATES || t == H - 1) {
+                if (polytope_violated<SX_MAX_M, NS>(cc.h_mat, cc.h_vec, cc.m, 1.0, p1, Q1, nullptr))
+                    con += SX_STATE_VIOLATION_COST;
+            }
+            const int64_t g = (int64_t)e * rp.P + c0 + tid;
+            if (valid && rp.traj) {
+                double* tr = rp.traj + (g * H + t) * S;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    tr[i] = p1[i];
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) tr[NS + i * NS + j] = Q1[i][j];
+                }
+            }
+            if (valid && rp.sigma) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) rp.sigma[(g * H + t) * NS + i] = var[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                p[i] = p1[i];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) Q[i][j] = Q1[i][j];
+            }
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = p[i];
+#pragma unroll
+                for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        const int64_t g = (int64_t)e * rp.P + c0 + tid;
+        rp.obj_cost[g] = obj;
+        rp.con_cost[g] = con;
+        if (st) atomicOr(rp.status, st);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_cem_rank_refit: one workgroup per problem.  128-bit radix select (con, obj) + index tie-break, then a bitonic
+// sort of the k survivors, then the refit.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kRankThreads = 1024;
+constexpr int kRankMaxK = 2048;
+
+__device__ __forceinline__ unsigned long long sortable_key(double x) {
+    if (x != x) return ~0ull;  // NaN last
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+struct RankArgs {
+    int P, k, row_len;
+    const double* con;
+    const double* obj;
+    long long cost_stride;
+    const double* actions;
+    long long act_stride;
+    int* elite_idx;
+    double* elite_rows;
+    double* mean;
+    double* std;
+    double* best;
+    int* best_ok;
+};
+
+__global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long sel_hi[kRankMaxK], sel_lo[kRankMaxK];
+    __shared__ int sel_idx[kRankMaxK];
+    __shared__ unsigned long long pref_hi, pref_lo;
+    __shared__ int need, n_less, n_tie_taken, sh_digit;
+    __shared__ int scan[kRankThreads];
+
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int P = ra.P, k = ra.k;
+    const double* con = ra.con + (long long)e * P * ra.cost_stride;
+    const double* obj = ra.obj + (long long)e * P * ra.cost_stride;
+    const double* act = ra.actions + (long long)e * P * ra.act_stride;
+
+    if (tid == 0) {
+        pref_hi = 0;
+        pref_lo = 0;
+        need = k;
+    }
+    __syncthreads();
+    // MSB-first radix select of the k-th smallest 128-bit key (hi = con, lo = obj)
+    for (int pass = 0; pass < 16; ++pass) {
+        const int shift = 56 - 8 * (pass & 7);
+        const bool in_hi = pass < 8;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long ph = pref_hi, pl = pref_lo;
+        for (int i = tid; i < P; i += kRankThreads) {
+            const unsigned long long kh = sortable_key(con[(long long)i * ra.cost_stride]);
+            const unsigned long long kl = sortable_key(obj[(long long)i * ra.cost_stride]);
+            bool match;
+            unsigned int digit;
+            if (in_hi) {
+                const unsigned long long mask = (pass == 0) ? 0ull : (~0ull << (shift + 8));
+                match = (kh & mask) == (ph & mask);
+                digit = (unsigned int)(kh >> shift) & 255u;
+            } else {
+                const unsigned long long mask = (pass == 8) ? 0ull : (~0ull << (shift + 8));
+                match = (kh == ph) && ((kl & mask) == (pl & mask));
+                digit = (unsigned int)(kl >> shift) & 255u;
+            }
+            if (match) atomicAdd(&hist[digit], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int rem = need;
+            int dsel = 255;
+            for (int dgt = 0; dgt < 256; ++dgt) {
+                const int cnt = (int)hist[dgt];
+                if (rem <= cnt) {
+                    dsel = dgt;
+                    break;
+                }
+                rem -= cnt;
+            }
+            need = rem;
+            sh_digit = dsel;
+            if (in_hi)
+                pref_hi |= ((unsigned long long)dsel) << shift;
+            else
+                pref_lo |= ((unsigned long long)dsel) << shift;
+        }
+        __syncthreads();
+    }
+    // (pref_hi, pref_lo) is the key of the k-th candidate; `need` of the candidates with exactly that key are taken,
+    // lowest index first.  Compact in index order: strictly-less first, then ties.
+    const unsigned long long th = pref_hi, tl = pref_lo;
+    const int tie_quota = need;
+    if (tid == 0) {
+        n_less = 0;
+        n_tie_taken = 0;
+    }
+    __syncthreads();
+    for (int base = 0; base < P; base += kRankThreads) {
+        const int i = base + tid;
+        unsigned long long kh = 0, kl = 0;
+        int cls = 0;  // 1 = strictly less, 2 = tie
+        if (i < P) {
+            kh = sortable_key(con[(long long)i * ra.cost_stride]);
+            kl = sortable_key(obj[(long long)i * ra.cost_stride]);
+            if (kh < th || (kh == th && kl < tl))
+                cls = 1;
+            else if (kh == th && kl == tl)
+                cls = 2;
+        }
+        // block-wide exclusive scans (Hillis-Steele in LDS) for the two classes, packed as (ties << 16 | less)
+        scan[tid] = (cls == 1 ? 1 : 0) | (cls == 2 ? (1 << 16) : 0);
+        __syncthreads();
+        for (int off = 1; off < kRankThreads; off <<= 1) {
+            const int v = (tid >= off) ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        const int incl = scan[tid];
+        const int total = scan[kRankThreads - 1];
+        const int less_before = n_less, tie_before = n_tie_taken;
+        if (cls == 1) {
+            const int slot = less_before + (incl & 0xffff) - 1;
+            sel_hi[slot] = kh;
+            sel_lo[slot] = kl;
+            sel_idx[slot] = i;
+        } else if (cls == 2) {
+            const int tie_rank = tie_before + (incl >> 16) - 1;
+            if (tie_rank < tie_quota) {
+                const int slot = (k - tie_quota) + tie_rank;
+                sel_hi[slot] = kh;
+                sel_lo[slot] = kl;
+                sel_idx[slot] = i;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            n_less = less_before + (total & 0xffff);
+            n_tie_taken = tie_before + (total >> 16);
+        }
+        __syncthreads();
+    }
+    // bitonic sort of the k selected entries by (hi, lo, idx); pad to a power of two with +inf keys
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    for (int i = k + tid; i < n2; i += kRankThreads) {
+        sel_hi[i] = ~0ull;
+        sel_lo[i] = ~0ull;
+        sel_idx[i] = 0x7fffffff;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (n2 >> 1); i += kRankThreads) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool asc = ((lo & size) == 0);
+                const unsigned long long ah = sel_hi[lo], al = sel_lo[lo], bh = sel_hi[hi], bl = sel_lo[hi];
+                const int ai = sel_idx[lo], bi = sel_idx[hi];
+                const bool a_gt_b = (ah > bh) || (ah == bh && (al > bl || (al == bl && ai > bi)));
+                if (a_gt_b == asc) {
+                    sel_hi[lo] = bh;
+                    sel_lo[lo] = bl;
+                    sel_idx[lo] = bi;
+                    sel_hi[hi] = ah;
+                    sel_lo[hi] = al;
+                    sel_idx[hi] = ai;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // outputs
+    const int L = ra.row_len;
+    if (ra.elite_idx)
+        for (int i = tid; i < k; i += kRankThreads) ra.elite_idx[(long long)e * k + i] = sel_idx[i];
+    if (ra.elite_rows) {
+        const int W = 2 + L;
+        for (int i = tid; i < k * W; i += kRankThreads) {
+            const int r = i / W, c = i - r * W;
+            const int src = sel_idx[r];
+            double v;
+            if (c == 0)
+                v = con[(long long)src * ra.cost_stride];
+            else if (c == 1)
+                v = obj[(long long)src * ra.cost_stride];
+            else
+                v = act[(long long)src * ra.act_stride + (c - 2)];
+            ra.elite_rows[((long long)e * k + r) * W + c] = v;
+        }
+    }
+    if (ra.mean) {
+        for (int c = tid; c < L; c += kRankThreads) {
+            double s = 0.0;
+            for (int r = 0; r < k; ++r) s += act[(long long)sel_idx[r] * ra.act_stride + c];
+            const double mu = s / k;
+            double ss = 0.0;
+            for (int r = 0; r < k; ++r) {
+                const double dv = act[(long long)sel_idx[r] * ra.act_stride + c] - mu;
+                ss += dv * dv;
+            }
+            ra.mean[(long long)e * L + c] = mu;
+            if (ra.std) ra.std[(long long)e * L + c] = (k > 1) ? sqrt(ss / (k - 1)) : 0.0;
+        }
+    }
+    if (ra.best)
+        for (int c = tid; c < L; c += kRankThreads) ra.best[(long long)e * L + c] = act[(long long)sel_idx[0] * ra.act_stride + c];
+    if (ra.best_ok && tid == 0) ra.best_ok[e] = (con[(long long)sel_idx[0] * ra.cost_stride] == 0.0) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side helpers
+// ---------------------------------------------------------------------------------------------------------------
+template <int NS, int NU>
+static GpConst<NS, NS + NU> make_gp_const(const sx_gp_model* m) {
+    constexpr int D = NS + NU;
+    GpConst<NS, D> gc;
+    for (int d = 0; d < NS; ++d) {
+        for (int j = 0; j < D; ++j) gc.inv_ls2[d * D + j] = m->inv_ls2[d * D + j];
+        gc.outputscale[d] = m->outputscale[d];
+        gc.noise[d] = m->noise[d];
+    }
+    gc.x_train = m->x_train;
+    gc.w_pack = m->w_pack;
+    gc.r_pack = m->r_pack;
+    gc.n_train = m->n_train;
+    gc.n_pad = m->n_pad;
+    return gc;
+}
+
+template <int NS, int NU>
+static bool make_reach_const(const sx_env* env, ReachConst<NS, NU>& rc) {
+    for (int i = 0; i < NS * NS; ++i) rc.a[i] = env->a[i];
+    for (int i = 0; i < NS * NU; ++i) rc.b[i] = env->b[i];
+    for (int i = 0; i < NU * NS; ++i) rc.kfb[i] = env->k_fb[i];
+    for (int i = 0; i < NS; ++i) {
+        rc.l_mu[i] = env->l_mu[i];
+        rc.l_sigma[i] = env->l_sigma[i];
+    }
+    rc.beta = env->beta;
+    // B = I + kfb^T kfb is SPD; lower Cholesky on the host
+    double B[NS][NS];
+    for (int i = 0; i < NS; ++i)
+        for (int j = 0; j < NS; ++j) {
+            double s = (i == j) ? 1.0 : 0.0;
+            for (int c = 0; c < NU; ++c) s += env->k_fb[c * NS + i] * env->k_fb[c * NS + j];
+            B[i][j] = s;
+        }
+    for (int i = 0; i < NS * NS; ++i) rc.cholB[i] = 0.0;
+    for (int j = 0; j < NS; ++j) {
+        double s = B[j][j];
+        for (int k = 0; k < j; ++k) s -= rc.cholB[j * NS + k] * rc.cholB[j * NS + k];
+        if (!(s > 0.0)) return false;
+        const double ljj = std::sqrt(s);
+        rc.cholB[j * NS + j] = ljj;
+        for (int i = j + 1; i < NS; ++i) {
+            double t = B[i][j];
+            for (int k = 0; k < j; ++k) t -= rc.cholB[i * NS + k] * rc.cholB[j * NS + k];
+            rc.cholB[i * NS + j] = t / ljj;
+        }
+    }
+    return true;
+}
+
+template <int NS, int NU>
+static void make_cost_const(const sx_env* env, CostConst<SX_MAX_M, NS, NU>& cc) {
+    std::memset(&cc, 0, sizeof(cc));
+    for (int r = 0; r < env->m; ++r) {
+        for (int i = 0; i < NS; ++i) cc.h_mat[r * NS + i] = env->h_mat[r * NS + i];
+        cc.h_vec[r] = env->h_vec[r];
+    }
+    for (int c = 0; c < NU; ++c) {
+        cc.u_min[c] = env->u_min[c];
+        cc.u_max[c] = env->u_max[c];
+    }
+    for (int i = 0; i < NS; ++i) {
+        cc.w_abs[i] = env->obj_w_abs[i];
+        cc.target[i] = env->obj_target[i];
+        cc.w_lin[i] = env->obj_w_lin[i];
+    }
+    cc.m = env->m;
+    cc.obj_mode = env->obj_mode;
+    cc.con_mode = env->con_mode;
+}
+
+static int check_launch() {
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        std::fprintf(stderr, "libsxamd: HIP launch error: %s\n", hipGetErrorString(err));
+        return SX_ERR_LAUNCH;
+    }
+    return SX_OK;
+}
+
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+    if (bytes > kMaxLdsBytes) return SX_ERR_UNSUPPORTED;
+    if (bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return SX_ERR_UNSUPPORTED;
+        }
+    }
+    return SX_OK;
+}
+
+template <int NS, int NU>
+static int launch_predict(const sx_gp_model* m, const double* z, int P, double* mean, double* var, double* jac,
+                          hipStream_t stream) {
+    auto gc = make_gp_const<NS, NU>(m);
+    const int nw = kPredictThreads / 64;
+    const size_t lds = gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) * sizeof(double);
+    if (int rc = allow_lds(gp_predict_kernel<NS, NU>, lds)) return rc;
+    const int tiles = (P + SX_TILE - 1) / SX_TILE;
+    const int grid = tiles < 4096 ? tiles : 4096;
+    hipLaunchKernelGGL((gp_predict_kernel<NS, NU>), dim3(grid), dim3(kPredictThreads), lds, stream, gc, z, P, mean, var,
+                       jac);
+    return check_launch();
+}
+
+template <int NS, int NU>
+static int launch_reach(const sx_env* env, int P, const double* p, const double* Q, const double* u, const double* mean,
+                        const double* var, const double* jac, double* p1, double* Q1, double* sigma, int* status,
+                        hipStream_t stream) {
+    ReachConst<NS, NU> rc;
+    if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
+    const int threads = 64;
+    hipLaunchKernelGGL((onestep_reach_kernel<NS, NU>), dim3((P + threads - 1) / threads), dim3(threads), 0, stream, rc,
+                       P, p, Q, u, mean, var, jac, p1, Q1, sigma, status);
+    return check_launch();
+}
+
+template <int NS>
+static int launch_polytope(const sx_env* env, int P, const double* p, const double* Q, double c_safety, double* d,
+                           uint8_t* inside, hipStream_t stream) {
+    PolyArgs<NS> pa;
+    std::memset(&pa, 0, sizeof(pa));
+    for (int r = 0; r < env->m; ++r) {
+        for (int i = 0; i < NS; ++i) pa.h_mat[r * NS + i] = env->h_mat[r * NS + i];
+        pa.h_vec[r] = env->h_vec[r];
+    }
+    pa.m = env->m;
+    const int threads = 64;
+    hipLaunchKernelGGL((polytope_kernel<NS>), dim3((P + threads - 1) / threads), dim3(threads), 0, stream, pa, P,
+                       c_safety, p, Q, d, inside);
+    return check_launch();
+}
+
+template <int NS, int NU>
+static int launch_rollout(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, hipStream_t stream) {
+    auto gc = make_gp_const<NS, NU>(m);
+    ReachConst<NS, NU> rc;
+    if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
+    CostConst<SX_MAX_M, NS, NU> cc;
+    make_cost_const<NS, NU>(env, cc);
+    const int nw = kRolloutThreads / 64;
+    const size_t lds =
+        (gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) + (size_t)SX_TILE * rp.H * NU) * sizeof(double);
+    if (int r = allow_lds(cem_rollout_kernel<NS, NU>, lds)) return r;
+    const int tiles = (rp.P + SX_TILE - 1) / SX_TILE;
+    hipLaunchKernelGGL((cem_rollout_kernel<NS, NU>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc, rc, cc,
+                       rp);
+    return check_launch();
+}
+
+}  // namespace sx
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+#define SX_DISPATCH(ns, nu, CALL)                              \
+    do {                                                       \
+        if ((ns) == 2 && (nu) == 1) return CALL(2, 1);         \
+        if ((ns) == 4 && (nu) == 1) return CALL(4, 1);         \
+        if ((ns) == 2 && (nu) == 2) return CALL(2, 2);         \
+        if ((ns) == 4 && (nu) == 2) return CALL(4, 2);         \
+        if ((ns) == 3 && (nu) == 1) return CALL(3, 1);         \
+        if ((ns) == 1 && (nu) == 1) return CALL(1, 1);         \
+        return SX_ERR_UNSUPPORTED;                             \
+    } while (0)
+
+extern "C" {
+
+const char* sx_version(void) { return "sxamd 0.1 gfx950"; }
+
+int sx_gp_pack_sizes(int n_s, int n_train, int64_t* w_doubles, int64_t* r_doubles) {
+    if (n_s <= 0 || n_s > SX_MAX_NS || n_train <= 0) return SX_ERR_ARG;
+    const int n_pad = (n_train + 15) / 16 * 16;
+    if (w_doubles) *w_doubles = sx::w_pack_doubles(n_s, n_pad);
+    if (r_doubles) *r_doubles = sx::r_pack_doubles(n_s, n_pad);
+    return SX_OK;
+}
+
+int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void* stream) {
+    if (!model || !linv || !alpha || !model->x_train || !model->w_pack || !model->r_pack) return SX_ERR_ARG;
+    if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)
+        return SX_ERR_ARG;
+    model->n_pad = (model->n_train + 15) / 16 * 16;
+    const int D = model->n_s + model->n_u;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t wt = sx::w_pack_doubles(model->n_s, model->n_pad);
+    int grid = (int)((wt + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(sx::pack_w_kernel, dim3(grid), dim3(256), 0, s, linv, model->n_s, model->n_train, model->n_pad,
+                       const_cast<double*>(model->w_pack));
+    sx::PackRArgs<SX_MAX_NS, SX_MAX_D> args;
+    std::memset(&args, 0, sizeof(args));
+    for (int i = 0; i < model->n_s * D; ++i) args.inv_ls2[i] = model->inv_ls2[i];
+    const int64_t rt = sx::r_pack_doubles(model->n_s, model->n_pad);
+    grid = (int)((rt + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(sx::pack_r_kernel, dim3(grid), dim3(256), 0, s, alpha, model->x_train, args, model->n_s, D,
+                       model->n_train, model->n_pad, const_cast<double*>(model->r_pack));
+    return sx::check_launch();
+}
+
+int sx_gp_predict(const sx_gp_model* model, const double* z, int P, double* mean, double* var, double* jac,
+                  void* stream) {
+    if (!model || !z || !mean || !var || P < 0) return SX_ERR_ARG;
+    if (P == 0) return SX_OK;
+#define CALL(NS, NU) sx::launch_predict<NS, NU>(model, z, P, mean, var, jac, (hipStream_t)stream)
+    SX_DISPATCH(model->n_s, model->n_u, CALL);
+#undef CALL
+}
+
+int sx_onestep_reach(const sx_env* env, int P, const double* p, const double* Q, const double* u, const double* mean,
+                     const double* var, const double* jac, double* p1, double* Q1, double* sigma, int32_t* status,
+                     void* stream) {
+    if (!env || !p || !u || !mean || !var || !p1 || !Q1 || !sigma || !status || P < 0) return SX_ERR_ARG;
+    if (Q && !jac) return SX_ERR_ARG;
+    if (P == 0) return SX_OK;
+#define CALL(NS, NU) \
+    sx::launch_reach<NS, NU>(env, P, p, Q, u, mean, var, jac, p1, Q1, sigma, status, (hipStream_t)stream)
+    SX_DISPATCH(env->n_s, env->n_u, CALL);
+#undef CALL
+}
+
+int sx_polytope_distance(const sx_env* env, int P, const double* p, const double* Q, double c_safety, double* d,
+                         uint8_t* inside, void* stream) {
+    if (!env || !p || !Q || !d || P < 0) return SX_ERR_ARG;
+    if (env->m <= 0 || env->m > SX_MAX_M) return SX_ERR_UNSUPPORTED;
+    if (P == 0) return SX_OK;
+    switch (env->n_s) {
+        case 1: return sx::launch_polytope<1>(env, P, p, Q, c_safety, d, inside, (hipStream_t)stream);
+        case 2: return sx::launch_polytope<2>(env, P, p, Q, c_safety, d, inside, (hipStream_t)stream);
+        case 3: return sx::launch_polytope<3>(env, P, p, Q, c_safety, d, inside, (hipStream_t)stream);
+        case 4: return sx::launch_polytope<4>(env, P, p, Q, c_safety, d, inside, (hipStream_t)stream);
+        default: return SX_ERR_UNSUPPORTED;
+    }
+}
+
+int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
+                   const double* mean, const double* std, const double* noise, double* actions, double* traj,
+                   double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream) {
+    if (!model || !env || !x0 || !actions || !obj_cost || !con_cost || !status) return SX_ERR_ARG;
+    if (E <= 0 || P <= 0 || H <= 0) return SX_ERR_ARG;
+    if (noise && (!mean || !std)) return SX_ERR_ARG;
+    if (model->n_s != env->n_s || model->n_u != env->n_u) return SX_ERR_ARG;
+    if (env->m <= 0 || env->m > SX_MAX_M) return SX_ERR_UNSUPPORTED;
+    sx::RolloutPtrs rp{x0, q0, mean, std, noise, actions, traj, sigma, obj_cost, con_cost, status, E, P, H};
+#define CALL(NS, NU) sx::launch_rollout<NS, NU>(model, env, rp, (hipStream_t)stream)
+    SX_DISPATCH(model->n_s, model->n_u, CALL);
+#undef CALL
+}
+
+int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, const double* obj_cost,
+                      int64_t cost_stride, const double* actions, int64_t act_stride, int32_t* elite_idx,
+                      double* elite_rows, double* mean, double* std, double* best, int32_t* best_ok, void* stream) {
+    if (!con_cost || !obj_cost || !actions || E <= 0 || P <= 0 || k <= 0 || row_len <= 0) return SX_ERR_ARG;
+    if (k > P) return SX_ERR_ARG;
+    if (k > sx::kRankMaxK) return SX_ERR_UNSUPPORTED;
+    sx::RankArgs ra{P,      k,          row_len,    con_cost, obj_cost, (long long)cost_stride,
+                    actions, (long long)act_stride, elite_idx, elite_rows, mean,     std,
+                    best,   best_ok};
+    hipLaunchKernelGGL(sx::cem_rank_kernel, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
+    return sx::check_launch();
+}
+
+}  // extern "C"

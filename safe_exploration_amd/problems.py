@@ -1,0 +1,150 @@
+"""Seeded synthetic problem instances with the constants of the reference's environments.
+
+Used by bench.py, the smoke test and the parity tests so that the HIP path and the oracle see identical inputs.
+Environment constants cite the reference (``safe_exploration/environments/environments.py``); the training sets
+are synthetic (there is no simulator on the path), the GP hyper-parameters are fixed, not fitted.
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import scipy.signal
+
+from . import _lib
+from .utils import dlqr
+
+
+@dataclass
+class ProblemSpec:
+    name: str
+    n_s: int
+    n_u: int
+    X: np.ndarray            # [N x D]
+    Y: np.ndarray            # [N x n_s]  error to the linear prior
+    lengthscale: np.ndarray  # [n_s x D]
+    outputscale: np.ndarray  # [n_s]
+    noise: np.ndarray        # [n_s]
+    a: np.ndarray
+    b: np.ndarray
+    k_fb: np.ndarray
+    l_mu: np.ndarray
+    l_sigma: np.ndarray
+    beta: float
+    h_mat: np.ndarray
+    h_vec: np.ndarray
+    u_min: np.ndarray
+    u_max: np.ndarray
+    obj_mode: int = _lib.SX_OBJ_NEG_VARIANCE
+    obj_w_abs: Optional[np.ndarray] = None
+    obj_target: Optional[np.ndarray] = None
+    obj_w_lin: Optional[np.ndarray] = None
+    con_mode: int = _lib.SX_CON_ALL_STATES
+    x0_std: float = 0.05
+    extra: dict = field(default_factory=dict)
+
+
+def synthetic_training_set(n: int, n_s: int, n_u: int, seed: int = 0, scale=0.5):
+    """X ~ U(-scale, scale)^D (the range of the reference's invpend_data.npz), smooth y plus N(0, 0.01^2) noise."""
+    rng = np.random.default_rng(seed)
+    d_in = n_s + n_u
+    scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), (d_in,))
+    X = rng.uniform(-1.0, 1.0, size=(n, d_in)) * scale
+    Wm = rng.normal(size=(d_in, n_s)) * 0.3
+    Y = np.sin((X / scale) @ Wm * 0.5) * 0.2 + 0.05 * np.cos(3.0 * X[:, :n_s] / scale[:n_s]) \
+        + rng.normal(size=(n, n_s)) * 0.01
+    return X, Y
+
+
+def _discretize(a_ct, b_ct, dt):
+    n_s, n_u = b_ct.shape
+    a, b, _, _, _ = scipy.signal.cont2discrete((a_ct, b_ct, np.eye(n_s), np.zeros((n_s, n_u))), dt)
+    return a, b
+
+
+def pendulum(n_train: int = 200, seed: int = 0, obj_mode: int = _lib.SX_OBJ_NEG_VARIANCE, beta: float = 3.0,
+             simple_constraints: bool = True) -> ProblemSpec:
+    """Inverted pendulum: state (d_theta, theta), one torque.  Constants: environments.py:403-482 (l=.5, g=9.82, dt=.05,
+    u in [-1, 1], l_mu = l_sigm = [.05, .02]), polytope :779-831, prior mass .1 and LQR weights
+    diag(1, 2) / 25 (experiments/journal_experiment_configs/episodic_pendulum_cem.py:32-58)."""
+    n_s, n_u = 2, 1
+    l, g, dt, m_prior, friction = 0.5, 9.82, 0.05, 0.1, 0.0
+    inertia = m_prior * l * l
+    a_ct = np.array([[-friction / inertia, g / l], [1.0, 0.0]])   # linearised at the upright position
+    b_ct = np.array([[1.0 / inertia], [0.0]])
+    a, b = _discretize(a_ct, b_ct, dt)
+    k_fb = -dlqr(a, b, np.diag([1.0, 2.0]), 25.0 * np.eye(1))[0]
+    max_rad = np.deg2rad(20.0)
+    if simple_constraints:   # |d_theta| <= 0.8, |theta| <= 20 deg (the hull of (+-0.8, +-20 deg))
+        h_mat = np.array([[1., 0.], [-1., 0.], [0., 1.], [0., -1.]])
+        h_vec = np.array([[0.8], [0.8], [max_rad], [max_rad]])
+    else:                    # the rhombus (-1.2, 20deg), (0.8, 0), (1.2, -20deg), (-0.8, 0): outward normals
+        corners = np.array([[-1.2, max_rad], [0.8, 0.0], [1.2, -max_rad], [-0.8, 0.0]])
+        h_rows, h_rhs = [], []
+        centre = corners.mean(0)
+        for i in range(4):
+            p0, p1 = corners[i], corners[(i + 1) % 4]
+            nrm = np.array([p1[1] - p0[1], -(p1[0] - p0[0])])
+            nrm /= np.linalg.norm(nrm)
+            if nrm @ (centre - p0) > 0:
+                nrm = -nrm
+            h_rows.append(nrm)
+            h_rhs.append(nrm @ p0)
+        h_mat, h_vec = np.array(h_rows), np.array(h_rhs)[:, None]
+    X, Y = synthetic_training_set(n_train, n_s, n_u, seed=seed, scale=0.5)
+    spec = ProblemSpec('pendulum', n_s, n_u, X, Y, np.full((n_s, 3), 0.7), np.full(n_s, 0.01), np.full(n_s, 1e-5), a, b,
+                       k_fb, np.array([.05, .02]), np.array([.05, .02]), beta, h_mat, h_vec, np.array([-1.0]),
+                       np.array([1.0]), obj_mode=obj_mode)
+    if obj_mode == _lib.SX_OBJ_AFFINE_ABS:   # |theta_target - theta| (environments.py:505-510), first objective -0.1
+        spec.obj_w_abs, spec.obj_target, spec.obj_w_lin = np.array([0., 1.]), np.array([0., -0.1]), np.zeros(2)
+    return spec
+
+
+def cartpole(n_train: int = 2000, seed: int = 2, beta: float = 2.0) -> ProblemSpec:
+    """Cart-pole: state (x, dx, theta, dtheta), one force.  Constants: environments.py:880-941 (l=.5, m=.5, M=.5, b=.1,
+    dt=.1, u in [-4, 4], l_mu = l_sigm = [.05]*4), Jacobian :1049-1066, 9-row polytope :1068-1116 (un-normalised:
+    defaultconfig_episode.py:61-62 sets norm_x = 1), LQR diag(2, 6, 12, 4) / 40 and beta 2 (:65-71)."""
+    n_s, n_u = 4, 1
+    l, m, M, fr, g, dt = 0.5, 0.55, 0.5, 0.1, 9.82, 0.1
+    a_ct = np.array([[0, 1, 0, 0], [0, 0, .5 * g * m / M, -fr * .5 / (M * l)], [0, 0, 0, 1],
+                     [0, 0, g * (m + M) / (l * M), -fr * (m + M) / (m * M * l ** 2)]])
+    b_ct = np.array([0, 1. / M, 0, 1 / (M * l)]).reshape(-1, 1)
+    a, b = _discretize(a_ct, b_ct, dt)
+    k_fb = -dlqr(a, b, np.diag([2.0, 6.0, 12.0, 4.0]), 40.0 * np.eye(1))[0]
+    h_mat = np.array([[0., 0., 7.25, 1.], [0., 0., -7.25, -1.], [0., 0., -1.25, -1.], [0., 0., 1.25, 1.],
+                      [0., 1., 0., 0.], [0., -1., 0., 0.], [1., 0., 0., 0.], [-1., 0., 0., 0.], [1., 2., 0., 0.]])
+    h_vec = np.array([1., 1., 1., 1., 1.66, 1.66, 2.6, 4.0, 3.0])[:, None]
+    X, Y = synthetic_training_set(n_train, n_s, n_u, seed=seed, scale=np.array([2.0, 1.5, 0.4, 1.0, 2.0]))
+    ls = np.tile(np.array([[4.0, 3.0, 0.8, 2.0, 4.0]]), (n_s, 1)) * np.array([[1.0], [1.1], [0.9], [1.2]])
+    return ProblemSpec('cartpole', n_s, n_u, X, Y, ls, np.full(n_s, 0.01), np.full(n_s, 1e-5), a, b, k_fb,
+                       np.full(4, .05), np.full(4, .05), beta, h_mat, h_vec, np.array([-4.0]), np.array([4.0]))
+
+
+def build(spec: ProblemSpec, device='cuda:0'):
+    """(GpCemSSM with the spec's data and hyper-parameters on `device`, sx_env)."""
+    import torch
+
+    from .gp_reachability_pytorch import make_env
+    from .ssm_cem.gp_ssm_cem import GpCemSSM
+
+    class _Conf:
+        exact_gp_training_iterations = 0
+        exact_gp_kernel = 'rbf'
+
+    _Conf.device = str(device)
+    ssm = GpCemSSM(_Conf(), spec.n_s, spec.n_u)
+    ssm.set_hyperparameters(spec.lengthscale, spec.outputscale, spec.noise)
+    ssm.update_model(torch.tensor(spec.X, dtype=torch.float64, device=device),
+                     torch.tensor(spec.Y, dtype=torch.float64, device=device), replace_old=True)
+    env = make_env(spec.n_s, spec.n_u, a=spec.a, b=spec.b, k_fb=spec.k_fb, l_mu=spec.l_mu, l_sigma=spec.l_sigma,
+                   beta=spec.beta, h_mat=spec.h_mat, h_vec=spec.h_vec, u_min=spec.u_min, u_max=spec.u_max,
+                   obj_mode=spec.obj_mode, obj_w_abs=spec.obj_w_abs, obj_target=spec.obj_target,
+                   obj_w_lin=spec.obj_w_lin, con_mode=spec.con_mode)
+    return ssm, env
+
+
+def oracle_problem(spec: ProblemSpec, ocem):
+    """The same constants as an ``oracle.cem.Problem`` (the caller passes the oracle module: this package never
+    imports it)."""
+    return ocem.Problem(spec.n_s, spec.n_u, spec.a, spec.b, spec.k_fb, spec.l_mu, spec.l_sigma, spec.beta, spec.h_mat,
+                        spec.h_vec, spec.u_min, spec.u_max, obj_mode=spec.obj_mode, obj_w_abs=spec.obj_w_abs,
+                        obj_target=spec.obj_target, obj_w_lin=spec.obj_w_lin, con_mode=spec.con_mode)

@@ -1,0 +1,194 @@
+"""Exact-GP state-space model for the CEM safe-MPC solver, predicted by the HIP kernels of libsxamd.
+
+Same surface as the reference's ``GpCemSSM`` (``safe_exploration/ssm_cem/gp_ssm_cem.py:17-137``): ``n_s`` independent
+exact GPs on shared inputs, zero mean, scaled ARD-RBF kernel, Gaussian likelihood whose noise is INCLUDED in the
+predictive variance.  The reference delegates the arithmetic to gpytorch 0.3.2; here
+
+* ``_update_model`` factorises ``K_d + noise_d I = L_d L_d^T`` and lays ``W_d = L_d^-1`` and ``alpha_d`` out for the
+  f64 matrix cores (``sx_gp_pack``) -- this is the warm path, run once per ``update_model``;
+* every ``predict_*`` is one ``sx_gp_predict`` launch (mean, variance and the analytic mean-Jacobian in one pass,
+  where the reference needs two forward passes and a backward pass, ``gp_ssm_cem.py:59-73``).
+
+Hyper-parameters follow gpytorch's parameterisation (softplus of a raw parameter that starts at 0; the noise has a
+1e-4 floor).  gpytorch is not available to check these defaults against: "parity unpinned" (DESIGN.md).
+"""
+import ctypes
+import math
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import _lib
+from ..utils import assert_shape, get_device
+from .ssm_cem import CemSSM
+
+_NOISE_FLOOR = 1e-4
+
+
+class GpCemSSM(CemSSM):
+    def __init__(self, conf, state_dimen: int, action_dimen: int, model=None):
+        super().__init__(state_dimen, action_dimen)
+        if model is not None:
+            raise NotImplementedError('injecting a gpytorch model is not supported: the GP is evaluated by libsxamd')
+        kernel = getattr(conf, 'exact_gp_kernel', 'rbf')
+        if kernel != 'rbf':
+            raise NotImplementedError(f'kernel {kernel!r}: only the ARD-RBF kernel has a HIP implementation')
+        if state_dimen > _lib.SX_MAX_NS or action_dimen > _lib.SX_MAX_NU:
+            raise ValueError(f'state/action dimension ({state_dimen}, {action_dimen}) beyond the compiled limits')
+        self._device = torch.device(get_device(conf))
+        self._training_iterations = int(getattr(conf, 'exact_gp_training_iterations', 0))
+        d_in = state_dimen + action_dimen
+        self._raw_lengthscale = torch.zeros((state_dimen, d_in), dtype=torch.float64)
+        self._raw_outputscale = torch.zeros((state_dimen,), dtype=torch.float64)
+        self._raw_noise = torch.zeros((state_dimen,), dtype=torch.float64)
+        self._noise_floor = _NOISE_FLOOR
+        self._last_training_losses = []
+        self._model: Optional[_lib.SxGpModel] = None
+        self._buffers = ()  # keeps the device operands alive while the struct points at them
+
+    # ---- hyper-parameters --------------------------------------------------------------------------------------
+    @property
+    def lengthscale(self) -> Tensor:
+        return F.softplus(self._raw_lengthscale)
+
+    @property
+    def outputscale(self) -> Tensor:
+        return F.softplus(self._raw_outputscale)
+
+    @property
+    def noise(self) -> Tensor:
+        return F.softplus(self._raw_noise) + self._noise_floor
+
+    @staticmethod
+    def _inv_softplus(x: Tensor) -> Tensor:
+        return x + torch.log(-torch.expm1(-x))
+
+    def set_hyperparameters(self, lengthscale=None, outputscale=None, noise=None) -> None:
+        """Explicit hyper-parameters: lengthscale [n_s x D] (or broadcastable), outputscale [n_s], noise [n_s]."""
+        n_s, d_in = self.num_states, self.num_states + self.num_actions
+        if lengthscale is not None:
+            ls = torch.as_tensor(lengthscale, dtype=torch.float64).cpu().expand(n_s, d_in).clone()
+            self._raw_lengthscale = self._inv_softplus(ls)
+        if outputscale is not None:
+            s = torch.as_tensor(outputscale, dtype=torch.float64).cpu().expand(n_s).clone()
+            self._raw_outputscale = self._inv_softplus(s)
+        if noise is not None:
+            nz = torch.as_tensor(noise, dtype=torch.float64).cpu().expand(n_s).clone()
+            if (nz <= 0).any():
+                raise ValueError('noise must be positive')
+            if (nz <= self._noise_floor).any():
+                self._noise_floor = 0.0   # explicit values below gpytorch's default floor: drop the floor
+            self._raw_noise = self._inv_softplus(nz - self._noise_floor)
+        if self._x_train is not None:
+            self._update_model(self._x_train, self._y_train)
+
+    # ---- model (re)build: the warm path ------------------------------------------------------------------------
+    def _kernel_matrices(self, x: Tensor, lengthscale: Tensor, outputscale: Tensor, noise: Tensor) -> Tensor:
+        """[n_s x N x N]  K_d + noise_d I."""
+        xs = x.unsqueeze(0) / lengthscale.unsqueeze(1)                      # [n_s x N x D]
+        sq = torch.cdist(xs, xs, compute_mode='donot_use_mm_for_euclid_dist').pow(2)
+        k = outputscale.view(-1, 1, 1) * torch.exp(-0.5 * sq)
+        return k + noise.view(-1, 1, 1) * torch.eye(x.size(0), dtype=x.dtype, device=x.device)
+
+    def _update_model(self, x_train: Tensor, y_train: Tensor) -> None:
+        _lib.require_gpu(x_train, 'train_x')
+        _lib.require_gpu(y_train, 'train_y')
+        lib = _lib.lib()
+        dev = x_train.device
+        n_s, n_u, n = self.num_states, self.num_actions, x_train.size(0)
+        x = x_train.detach().contiguous()
+        y = y_train.detach()
+        ls, s, nz = self.lengthscale.to(dev), self.outputscale.to(dev), self.noise.to(dev)
+        k = self._kernel_matrices(x, ls, s, nz)
+        chol = torch.linalg.cholesky(k)                                     # [n_s x N x N] lower
+        eye = torch.eye(n, dtype=torch.float64, device=dev).expand(n_s, n, n)
+        linv = torch.linalg.solve_triangular(chol, eye, upper=False).contiguous()
+        alpha = torch.cholesky_solve(y.t().unsqueeze(2), chol).squeeze(2).contiguous()  # [n_s x N]
+
+        w_n, r_n = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.sx_gp_pack_sizes(n_s, n, ctypes.byref(w_n), ctypes.byref(r_n)), 'sx_gp_pack_sizes')
+        w_pack = torch.empty(w_n.value, dtype=torch.float64, device=dev)
+        r_pack = torch.empty(r_n.value, dtype=torch.float64, device=dev)
+        m = _lib.SxGpModel()
+        m.n_s, m.n_u, m.n_train = n_s, n_u, n
+        _lib.fill(m.inv_ls2, (1.0 / self.lengthscale ** 2).numpy())
+        _lib.fill(m.outputscale, self.outputscale.numpy())
+        _lib.fill(m.noise, self.noise.numpy())
+        m.x_train, m.w_pack, m.r_pack = x.data_ptr(), w_pack.data_ptr(), r_pack.data_ptr()
+        _lib.check(lib.sx_gp_pack(ctypes.byref(m), _lib.ptr(linv), _lib.ptr(alpha), _lib.stream_ptr(dev)), 'sx_gp_pack')
+        self._model = m
+        self._buffers = (x, w_pack, r_pack, linv, alpha)
+
+    @property
+    def device_model(self) -> _lib.SxGpModel:
+        """The sx_gp_model the fused solver hands to sx_cem_rollout."""
+        if self._model is None:
+            raise RuntimeError('the GP has no training data yet: call update_model first')
+        return self._model
+
+    def _train_model(self, x_train: Tensor, y_train: Tensor) -> None:
+        """Adam (lr 0.01) on the exact marginal log likelihood, as the reference does (gp_ssm_cem.py:103-129)."""
+        if self._training_iterations <= 0:
+            return
+        dev = x_train.device
+        x, y = x_train.detach(), y_train.detach().t()                       # y [n_s x N]
+        n = x.size(0)
+        raw = [t.clone().to(dev).requires_grad_(True) for t in
+               (self._raw_lengthscale, self._raw_outputscale, self._raw_noise)]
+        opt = torch.optim.Adam(raw, lr=0.01)
+        losses = []
+        for _ in range(self._training_iterations):
+            opt.zero_grad()
+            k = self._kernel_matrices(x, F.softplus(raw[0]), F.softplus(raw[1]), F.softplus(raw[2]) + self._noise_floor)
+            chol = torch.linalg.cholesky(k)
+            alpha = torch.cholesky_solve(y.unsqueeze(2), chol).squeeze(2)
+            mll = -0.5 * (y * alpha).sum(1) - torch.log(torch.diagonal(chol, dim1=1, dim2=2)).sum(1) \
+                - 0.5 * n * math.log(2 * math.pi)
+            loss = -(mll / n).sum()
+            loss.backward()
+            losses.append(loss.item())
+            opt.step()
+        self._raw_lengthscale, self._raw_outputscale, self._raw_noise = (t.detach().cpu() for t in raw)
+        self._last_training_losses = losses
+        self._update_model(x_train, y_train)
+
+    # ---- prediction: the hot path ------------------------------------------------------------------------------
+    def _predict_z(self, z: Tensor, jacobians: bool) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        n = z.size(0)
+        d_in = self.num_states + self.num_actions
+        assert_shape(z, (n, d_in))
+        _lib.require_gpu(z, 'states/actions')
+        z = z.detach().contiguous()
+        mean = torch.empty((n, self.num_states), dtype=torch.float64, device=z.device)
+        var = torch.empty_like(mean)
+        jac = torch.empty((n, self.num_states, d_in), dtype=torch.float64, device=z.device) if jacobians else None
+        if self._model is None:
+            # no data: the prior (zero mean, s + noise variance, flat mean)
+            mean.zero_()
+            var.copy_((self.outputscale + self.noise).to(z.device).expand(n, -1))
+            if jac is not None:
+                jac.zero_()
+            return mean, var, jac
+        _lib.check(_lib.lib().sx_gp_predict(ctypes.byref(self._model), _lib.ptr(z), n, _lib.ptr(mean), _lib.ptr(var),
+                                            _lib.ptr(jac), _lib.stream_ptr(z.device)), 'sx_gp_predict')
+        return mean, var, jac
+
+    def predict_with_jacobians(self, states: Tensor, actions: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        return self._predict_z(self._join_states_actions(states, actions), True)
+
+    def predict_without_jacobians(self, states: Tensor, actions: Tensor) -> Tuple[Tensor, Tensor]:
+        mean, var, _ = self._predict_z(self._join_states_actions(states, actions), False)
+        return mean, var
+
+    def predict_raw(self, z: Tensor) -> Tuple[Tensor, Tensor]:
+        mean, var, _ = self._predict_z(z, False)
+        return mean.t(), var.t()
+
+    def collect_metrics(self) -> Dict[str, Any]:
+        return {'losses': self._last_training_losses}
+
+    @property
+    def parametric(self) -> bool:
+        return False

@@ -1,0 +1,82 @@
+"""State-space-model interface consumed by the CEM safe-MPC solver (torch tensors in, torch tensors out).
+
+Mirrors the surface of the reference's ``safe_exploration/ssm_cem/ssm_cem.py:11-131`` so a model written against one
+works with the other.
+"""
+from abc import ABC, abstractmethod
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ..utils import assert_shape
+
+
+class CemSSM(ABC):
+    def __init__(self, state_dimen: int, action_dimen: int):
+        self.num_states = state_dimen
+        self.num_actions = action_dimen
+        self._x_train: Optional[Tensor] = None
+        self._y_train: Optional[Tensor] = None
+
+    # ---- training data -------------------------------------------------------------------------------------------
+    @property
+    def x_train(self) -> Optional[Tensor]:
+        return self._x_train
+
+    @property
+    def y_train(self) -> Optional[Tensor]:
+        return self._y_train
+
+    def update_model(self, train_x: Tensor, train_y: Tensor, opt_hyp=False, replace_old=False) -> None:
+        """train_x [N x (n_s+n_u)], train_y [N x n_s]; merges with the stored data unless replace_old.
+
+        Hyper-parameters are re-fitted when opt_hyp is set or the model is parametric.
+        """
+        n = train_x.size(0)
+        assert_shape(train_x, (n, self.num_states + self.num_actions))
+        assert_shape(train_y, (n, self.num_states))
+        if not replace_old and self._x_train is not None and self._y_train is not None:
+            train_x = torch.cat((self._x_train, train_x), dim=0)
+            train_y = torch.cat((self._y_train, train_y), dim=0)
+        self._x_train, self._y_train = train_x, train_y
+        self._update_model(train_x, train_y)
+        if opt_hyp or self.parametric:
+            self._train_model(train_x, train_y)
+
+    @abstractmethod
+    def _update_model(self, x_train: Tensor, y_train: Tensor) -> None:
+        ...
+
+    @abstractmethod
+    def _train_model(self, x_train: Tensor, y_train: Tensor) -> None:
+        ...
+
+    # ---- prediction ----------------------------------------------------------------------------------------------
+    @abstractmethod
+    def predict_with_jacobians(self, states: Tensor, actions: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """states [N x n_s], actions [N x n_u] -> mean [N x n_s], var [N x n_s], jac [N x n_s x (n_s+n_u)]."""
+
+    @abstractmethod
+    def predict_without_jacobians(self, states: Tensor, actions: Tensor) -> Tuple[Tensor, Tensor]:
+        """states [N x n_s], actions [N x n_u] -> mean [N x n_s], var [N x n_s]."""
+
+    @abstractmethod
+    def predict_raw(self, z: Tensor) -> Tuple[Tensor, Tensor]:
+        """z [N x (n_s+n_u)] -> mean [n_s x N], var [n_s x N] (outputs first, as the reference's GpCemSSM)."""
+
+    def _join_states_actions(self, states: Tensor, actions: Tensor) -> Tensor:
+        n = states.size(0)
+        assert_shape(states, (n, self.num_states))
+        assert_shape(actions, (n, self.num_actions))
+        return torch.cat((states, actions), dim=1)
+
+    # ---- bookkeeping ---------------------------------------------------------------------------------------------
+    @abstractmethod
+    def collect_metrics(self) -> Dict[str, Any]:
+        ...
+
+    @property
+    @abstractmethod
+    def parametric(self) -> bool:
+        ...

@@ -1,0 +1,217 @@
+"""GPU parity: the HIP path (through the C ABI / the boundary classes) against the oracle and the reference goldens.
+
+Tolerances (float64 end to end; the reference's own twin tests use np.allclose defaults rtol 1e-5 / atol 1e-8):
+  GP mean / variance / Jacobian   rtol 1e-9, atol 1e-11   (variance is a cancellation s - |W k|^2 + noise)
+  (p, Q, sigma) one step          rtol 1e-9, atol 1e-12
+  chained rollouts                rtol 1e-8, atol 1e-11
+  selected actions                1e-9 absolute (north_star asks for 1e-4)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cem as ocem
+from oracle import reachability as oreach
+from oracle.gp import ExactGP
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['onestep_pendulum_lin', 'onestep_pendulum_nolin', 'onestep_pendulum_env', 'onestep_cartpole_lin',
+         'onestep_cartpole_nolin']
+
+
+class Conf:
+    exact_gp_training_iterations = 0
+    exact_gp_kernel = 'rbf'
+    device = 'cuda:0'
+
+
+def T(x):
+    return torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device='cuda:0')
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + '.npz')))
+
+
+def make_ssm(X, Y, ls, s, noise, n_s, n_u):
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+    ssm = GpCemSSM(Conf(), n_s, n_u)
+    ssm.set_hyperparameters(ls, s, noise)
+    ssm.update_model(T(X), T(Y), replace_old=True)
+    return ssm
+
+
+def ssm_of(g):
+    n_s = g['p'].shape[1]
+    return make_ssm(g['X'], g['Y'], g['ls'], g['s'], g['noise'], n_s, g['k_ff'].shape[1])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_gp_predict_vs_oracle(golden_dir, name):
+    g = load(golden_dir, name)
+    ssm = ssm_of(g)
+    gp = ExactGP(g['X'], g['Y'], g['ls'], g['s'], g['noise'])
+    rng = np.random.default_rng(3)
+    D = g['X'].shape[1]
+    for P in (1, 5, 16, 37, 300):
+        z = rng.uniform(-0.6, 0.6, size=(P, D))
+        n_s = ssm.num_states
+        m, v, j = ssm.predict_with_jacobians(T(z[:, :n_s]), T(z[:, n_s:]))
+        mo, vo, jo = gp.predict(z)
+        np.testing.assert_allclose(m.cpu().numpy(), mo, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(v.cpu().numpy(), vo, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(j.cpu().numpy(), jo, rtol=1e-9, atol=1e-11)
+        m2, v2 = ssm.predict_without_jacobians(T(z[:, :n_s]), T(z[:, n_s:]))
+        assert torch.equal(m2, m) and torch.equal(v2, v)
+        mr, vr = ssm.predict_raw(T(z))
+        assert mr.shape == (n_s, P) and torch.equal(mr.t(), m) and torch.equal(vr.t(), v)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_onestep_reachability_vs_reference_golden(golden_dir, name):
+    from safe_exploration_amd.gp_reachability_pytorch import onestep_reachability
+    g = load(golden_dir, name)
+    ssm = ssm_of(g)
+    a, b = (T(g['a']), T(g['b'])) if bool(g['has_lin']) else (None, None)
+    args = (T(g['l_mu']), T(g['l_sigma']))
+    p1, q1, sig = onestep_reachability(T(g['p']), ssm, T(g['k_ff']), *args, None, T(g['k_fb']), float(g['c_safety']),
+                                       verbose=0, a=a, b=b)
+    np.testing.assert_allclose(p1.cpu().numpy(), g['point_p'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(q1.cpu().numpy(), g['point_q'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(sig.cpu().numpy(), g['point_sigma'], rtol=1e-9, atol=1e-12)
+    p1, q1, sig = onestep_reachability(T(g['p']), ssm, T(g['k_ff']), *args, T(g['q']), T(g['k_fb']),
+                                       float(g['c_safety']), verbose=0, a=a, b=b)
+    np.testing.assert_allclose(p1.cpu().numpy(), g['ell_p'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(q1.cpu().numpy(), g['ell_q'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(sig.cpu().numpy(), g['ell_sigma'], rtol=1e-9, atol=1e-12)
+    # sigma passthrough == GP variance at (p, k_ff) (test_gp_reachability_pytorch.py:139-159)
+    _, v = ssm.predict_without_jacobians(T(g['p']), T(g['k_ff']))
+    assert torch.allclose(sig, v)
+
+
+def env_from_golden(g, n_s, n_u, h_mat=None, h_vec=None, **kw):
+    from safe_exploration_amd.gp_reachability_pytorch import make_env
+    a, b = (g['a'], g['b']) if bool(g['has_lin']) else (np.eye(n_s), np.zeros((n_s, n_u)))
+    h_mat = np.eye(n_s) if h_mat is None else h_mat
+    h_vec = np.ones((n_s, 1)) if h_vec is None else h_vec
+    env = make_env(n_s, n_u, a=a, b=b, k_fb=g['k_fb'], l_mu=g['l_mu'], l_sigma=g['l_sigma'], beta=float(g['c_safety']),
+                   h_mat=h_mat, h_vec=h_vec, u_min=-np.ones(n_u), u_max=np.ones(n_u), **kw)
+    prob = ocem.Problem(n_s, n_u, a, b, g['k_fb'], g['l_mu'], g['l_sigma'], float(g['c_safety']), h_mat, h_vec,
+                        -np.ones(n_u), np.ones(n_u), **{k: v for k, v in kw.items()})
+    return env, prob
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_fused_rollout_vs_reference_chain(golden_dir, name):
+    """sx_cem_rollout with given actions reproduces the reference's chained onestep_reachability calls."""
+    from safe_exploration_amd.cem_mpc import cem_rollout
+    g = load(golden_dir, name)
+    n_s, n_u = g['p'].shape[1], g['k_ff'].shape[1]
+    ssm = ssm_of(g)
+    env, _ = env_from_golden(g, n_s, n_u)
+    P, H = g['actions'].shape[:2]
+    # each particle of the golden starts from its own point: run them as P problems of one particle
+    r = cem_rollout(ssm, env, T(g['p']), H, actions=T(g['actions']).view(P, 1, H, n_u), want_traj=True, want_sigma=True)
+    traj = r['traj'].cpu().numpy().reshape(P, H, -1)
+    np.testing.assert_allclose(traj[:, :, :n_s], g['chain_p'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(traj[:, :, n_s:].reshape(P, H, n_s, n_s), g['chain_q'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(r['sigma'].cpu().numpy().reshape(P, H, n_s), g['chain_sigma'], rtol=1e-8, atol=1e-11)
+    assert int(r['status'].item()) == 0
+
+
+def test_polytope_vs_reference_golden(golden_dir):
+    from safe_exploration_amd.gp_reachability_pytorch import (is_ellipsoid_inside_polytope,
+                                                              lin_ellipsoid_safety_distance)
+    g = load(golden_dir, 'polytope')
+    d = lin_ellipsoid_safety_distance(T(g['p']), T(g['q']), T(g['box_A']), T(g['box_b']))
+    assert d.shape == (3, 4)
+    np.testing.assert_allclose(d.cpu().numpy(), g['dist'], rtol=1e-12, atol=1e-13)
+    ins = is_ellipsoid_inside_polytope(T(g['p3']), T(g['q3']), T(g['box_A']), T(g['box_b']))
+    assert ins.shape == (3,) and ins.cpu().tolist() == [True, False, False]
+    d = lin_ellipsoid_safety_distance(T(g['pr']), T(g['qr']), T(g['hr']), T(g['hv']))
+    np.testing.assert_allclose(d.cpu().numpy(), g['dist_r'], rtol=1e-12, atol=1e-13)
+    ins = is_ellipsoid_inside_polytope(T(g['pr']), T(g['qr']), T(g['hr']), T(g['hv']))
+    assert (ins.cpu().numpy() == g['inside_r']).all()
+
+
+def pendulum_problem(N=200, seed=0, obj_mode=0):
+    """cfg-2 shaped synthetic problem: HIP-side (ssm, env) and oracle-side (gp, prob) twins."""
+    from safe_exploration_amd import problems
+    spec = problems.pendulum(n_train=N, seed=seed, obj_mode=obj_mode)
+    ssm, env = problems.build(spec, 'cuda:0')
+    gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+    return ssm, gp, env, problems.oracle_problem(spec, ocem)
+
+
+@pytest.mark.parametrize('obj_mode', [0, 1])
+@pytest.mark.parametrize('P,H', [(16, 4), (100, 7), (257, 15)])
+def test_fused_rollout_costs_vs_oracle(P, H, obj_mode):
+    from safe_exploration_amd.cem_mpc import cem_rollout
+    ssm, gp, env, prob = pendulum_problem(obj_mode=obj_mode)
+    rng = np.random.default_rng(P + H)
+    x0 = rng.normal(0, 0.05, size=2)
+    noise = rng.normal(size=(P, H, 1))
+    mean = rng.normal(0, 0.05, size=(H, 1))
+    std = rng.uniform(0.05, 0.6, size=(H, 1))
+    r = cem_rollout(ssm, env, T(x0[None]), H, mean=T(mean[None]), std=T(std[None]), noise=T(noise[None]),
+                    want_traj=True, want_sigma=True)
+    # the kernel may fuse mean + std * eps into one fma: compare the sample loosely, then roll the oracle out on
+    # exactly the actions the kernel used
+    actions = r['actions'][0].cpu().numpy()
+    np.testing.assert_allclose(actions, mean[None] + std[None] * noise, rtol=1e-13, atol=1e-16)
+    ref = ocem.rollout(prob, gp, x0, actions)
+    traj = r['traj'][0].cpu().numpy()
+    np.testing.assert_allclose(traj[:, :, :2], ref.traj_p, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(traj[:, :, 2:].reshape(P, H, 2, 2), ref.traj_q, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(r['sigma'][0].cpu().numpy(), ref.sigma, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(r['obj_cost'][0].cpu().numpy(), ref.obj_cost, rtol=1e-8, atol=1e-11)
+    np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
+    if H <= 7:  # long horizons are infeasible for this problem (ellipsoids outgrow the polytope): only costs there
+        assert (ref.con_cost > 0).any() and (ref.con_cost == 0).any()
+    assert ref.status == 0 and int(r['status'].item()) == 0
+
+
+@pytest.mark.parametrize('P,k,L', [(16, 3, 4), (1000, 10, 15), (4096, 409, 15), (5000, 1, 30), (333, 333, 6)])
+def test_rank_refit_vs_oracle(P, k, L):
+    from safe_exploration_amd.cem_mpc import cem_rank_refit
+    rng = np.random.default_rng(P + k)
+    E = 3
+    con = rng.choice([0., 0., 3., 10., 13., 20.], size=(E, P))
+    obj = rng.normal(size=(E, P))
+    nt = obj[:, 1::7].shape[1]
+    obj[:, 0:7 * nt:7] = obj[:, 1::7]                     # exact ties
+    con[1] = rng.choice([3., 10.], size=P)                # problem 1: nothing feasible
+    obj[2, 5] = np.nan
+    act = rng.normal(size=(E, P, L))
+    out = cem_rank_refit(T(con), T(obj), T(act), k, want_rows=True)
+    for e in range(E):
+        idx = ocem.rank(con[e], obj[e], k)
+        np.testing.assert_array_equal(out['elite_idx'][e].cpu().numpy(), idx)
+        m, s = ocem.refit(act[e][idx])
+        np.testing.assert_allclose(out['mean'][e].cpu().numpy(), m, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(out['std'][e].cpu().numpy(), s, rtol=1e-12, atol=1e-14)
+        np.testing.assert_array_equal(out['best'][e].cpu().numpy(), act[e][idx[0]])
+        assert int(out['best_ok'][e]) == int(con[e][idx[0]] == 0)
+        rows = out['elite_rows'][e].cpu().numpy()
+        np.testing.assert_array_equal(rows[:, 0], con[e][idx])
+        np.testing.assert_array_equal(rows[:, 2:], act[e][idx])
+
+
+def test_full_solve_vs_oracle():
+    """Whole get_actions loop with injected noise: elites, refits and the selected actions match the oracle."""
+    from safe_exploration_amd.cem_mpc import FusedCemMpc
+    ssm, gp, env, prob = pendulum_problem(obj_mode=1)
+    P, H, k, iters = 256, 6, 20, 4
+    rng = np.random.default_rng(5)
+    noise = rng.normal(size=(iters, P, H, 1))
+    x0 = np.array([0.02, -0.03])
+    mpc = FusedCemMpc(ssm, env, H, P, k, iters, device='cuda:0', init_std=0.2)
+    best, ok, _, status = mpc.solve(T(x0[None]), noise=T(noise[:, None]))
+    ref_best, trace = ocem.cem_solve(prob, gp, x0, noise, k, init_std=np.full((H, 1), 0.2))
+    assert int(status.item()) == 0
+    assert (ref_best is not None) == bool(ok[0])
+    assert ref_best is not None, 'test problem should be feasible'
+    np.testing.assert_allclose(best[0].cpu().numpy(), ref_best, rtol=0, atol=1e-9)

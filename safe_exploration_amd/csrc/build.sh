@@ -10,5 +10,5 @@ if [ -f "$OUT" ] && [ -z "$(find . ../../include -newer "$OUT" \( -name '*.hip' 
     exit 0
 fi
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-    -Wall -Wno-unused-function ${SX_EXTRA_FLAGS:-} -o "$OUT.tmp" $SRC
+    -mllvm -amdgpu-mfma-vgpr-form=1 -Wall -Wno-unused-function ${SX_EXTRA_FLAGS:-} -o "$OUT.tmp" $SRC
 mv "$OUT.tmp" "$OUT"

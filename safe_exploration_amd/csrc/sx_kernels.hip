@@ -81,10 +81,11 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpTileLds<NS, D> lds;
     const int nw = blockDim.x >> 6;
-    lds.carve(smem, gc.n_train, gc.n_pad, nw);
+    lds.carve(smem, gc.n_train, gc.n_pad, nw, gc.stage_cap);
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     gp_load_xs(gc, lds);
+    gp_build_stages(gc, lds, wave, nw, lane);
     for (int tile = blockIdx.x; tile * SX_TILE < P; tile += gridDim.x) {
         const int g0 = tile * SX_TILE;
         if (tid < SX_TILE * D) {
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpTileLds<NS, D> lds;
     const int nw = blockDim.x >> 6;
-    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw);  // [16][H][NU]
+    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw, gc.stage_cap);  // [16][H][NU]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int H = rp.H;
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     const int c0 = (blockIdx.x - e * tiles_per_problem) * SX_TILE;  // first particle of the tile within problem e
 
     gp_load_xs(gc, lds);
+    gp_build_stages(gc, lds, wave, nw, lane);
     // sample (or load) this tile's action sequences: a = mean + std * eps
     for (int i = tid; i < SX_TILE * H * NU; i += blockDim.x) {
         const int c = i / (H * NU);
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
 // host-side helpers
 // ---------------------------------------------------------------------------------------------------------------
 template <int NS, int NU>
-static GpConst<NS, NS + NU> make_gp_const(const sx_gp_model* m) {
+static GpConst<NS, NS + NU> make_gp_const(const sx_gp_model* m, int nw) {
     constexpr int D = NS + NU;
     GpConst<NS, D> gc;
     for (int d = 0; d < NS; ++d) {
@@ -566,6 +568,7 @@ static GpConst<NS, NS + NU> make_gp_const(const sx_gp_model* m) {
     gc.r_pack = m->r_pack;
     gc.n_train = m->n_train;
     gc.n_pad = m->n_pad;
+    gc.stage_cap = gp_stage_cap(NS, m->n_pad, nw);
     return gc;
 }
 
@@ -651,8 +654,9 @@ static int allow_lds(K kernel, size_t bytes) {
 template <int NS, int NU>
 static int launch_predict(const sx_gp_model* m, const double* z, int P, double* mean, double* var, double* jac,
                           hipStream_t stream) {
-    auto gc = make_gp_const<NS, NU>(m);
     const int nw = kPredictThreads / 64;
+    auto gc = make_gp_const<NS, NU>(m, nw);
+    if ((NS * ((m->n_pad >> 4) + 1) + nw - 1) / nw > 64) return SX_ERR_UNSUPPORTED;
     const size_t lds = gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) * sizeof(double);
     if (int rc = allow_lds(gp_predict_kernel<NS, NU>, lds)) return rc;
     const int tiles = (P + SX_TILE - 1) / SX_TILE;
@@ -692,12 +696,13 @@ static int launch_polytope(const sx_env* env, int P, const double* p, const doub
 
 template <int NS, int NU>
 static int launch_rollout(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, hipStream_t stream) {
-    auto gc = make_gp_const<NS, NU>(m);
+    const int nw = kRolloutThreads / 64;
+    auto gc = make_gp_const<NS, NU>(m, nw);
+    if ((NS * ((m->n_pad >> 4) + 1) + nw - 1) / nw > 64) return SX_ERR_UNSUPPORTED;
     ReachConst<NS, NU> rc;
     if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
     CostConst<SX_MAX_M, NS, NU> cc;
     make_cost_const<NS, NU>(env, cc);
-    const int nw = kRolloutThreads / 64;
     const size_t lds =
         (gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) + (size_t)SX_TILE * rp.H * NU) * sizeof(double);
     if (int r = allow_lds(cem_rollout_kernel<NS, NU>, lds)) return r;

@@ -59,8 +59,9 @@ typedef struct sx_gp_model {
     double outputscale[SX_MAX_NS];
     double noise[SX_MAX_NS];     /* likelihood noise, added to the predictive variance (gp_ssm_cem.py:93) */
     const double* x_train;       /* dev [N x D] */
-    const double* w_pack;        /* dev, sx_gp_pack_sizes() doubles: W_d in MFMA fragment order */
-    const double* r_pack;        /* dev: rows alpha_d, alpha_d * X_j / l_dj^2 in MFMA fragment order */
+    const double* a_pack;        /* dev, sx_gp_pack_sizes() doubles: W_d, then the rows alpha_d, alpha_d * X_j / l_dj^2,
+                                    in MFMA fragment order */
+    const int32_t* stage_tab;    /* dev, sx_gp_pack_sizes() int32: the static MFMA operand stream of every wave */
 } sx_gp_model;
 
 /* Environment / solver constants of one MPC problem.
@@ -90,11 +91,13 @@ typedef struct sx_env {
 /* Library / build identification: returns "sxamd <version> gfx950". */
 const char* sx_version(void);
 
-/* Doubles needed for sx_gp_model.w_pack / r_pack. */
-int sx_gp_pack_sizes(int n_s, int n_train, int64_t* w_doubles, int64_t* r_doubles);
+#define SX_WAVES 8               /* waves per workgroup in the GP kernels (the stage table is laid out for it) */
+
+/* Sizes of sx_gp_model.a_pack (doubles) and sx_gp_model.stage_tab (int32). */
+int sx_gp_pack_sizes(int n_s, int n_train, int64_t* a_doubles, int64_t* tab_ints);
 
 /* Lays W_d = L_d^-1 (dev [n_s x N x N], lower triangular) and alpha (dev [n_s x N]) out in fragment order.
- * model->{n_s,n_u,n_train,inv_ls2,x_train,w_pack,r_pack} must be set; n_pad is filled in.
+ * model->{n_s,n_u,n_train,inv_ls2,x_train,a_pack,stage_tab} must be set; n_pad is filled in.
  * Replaces: GpCemSSM._update_model (ssm_cem/gp_ssm_cem.py:96-101) -- where the prediction operands are (re)built. */
 int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void* stream);
 

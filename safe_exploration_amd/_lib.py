@@ -26,7 +26,7 @@ _ERR = {SX_ERR_ARG: 'bad argument (null pointer, non-positive size or inconsiste
 class SxGpModel(Structure):
     _fields_ = [('n_s', c_int32), ('n_u', c_int32), ('n_train', c_int32), ('n_pad', c_int32),
                 ('inv_ls2', c_double * (SX_MAX_NS * SX_MAX_D)), ('outputscale', c_double * SX_MAX_NS),
-                ('noise', c_double * SX_MAX_NS), ('x_train', c_void_p), ('w_pack', c_void_p), ('r_pack', c_void_p)]
+                ('noise', c_double * SX_MAX_NS), ('x_train', c_void_p), ('a_pack', c_void_p), ('stage_tab', c_void_p)]
 
 
 class SxEnv(Structure):
@@ -54,7 +54,8 @@ SIGNATURES = {
                           + [c_void_p] * 7),
 }
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libsxamd.so')
+# SX_LIB selects a diagnostic build of the same library (tools/phase_stamps.py); the default is the product build
+LIB_PATH = os.environ.get('SX_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libsxamd.so')
 _lib = None
 
 

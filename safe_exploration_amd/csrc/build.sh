@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-OUT=libsxamd.so
+OUT=${SX_OUT:-libsxamd.so}
 SRC="sx_kernels.hip"
 # rebuild only when a source is newer than the library
 if [ -f "$OUT" ] && [ -z "$(find . ../../include -newer "$OUT" \( -name '*.hip' -o -name '*.hpp' -o -name '*.h' -o -name 'build.sh' \) | head -1)" ]; then

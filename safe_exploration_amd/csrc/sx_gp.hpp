@@ -29,6 +29,9 @@ __host__ __device__ inline int64_t w_pack_doubles(int n_s, int n_pad) {
     return (int64_t)n_s * w_pairs_per_output(n_pad / 16) * 128;
 }
 __host__ __device__ inline int64_t r_pack_doubles(int n_s, int n_pad) { return (int64_t)n_s * (n_pad / 8) * 128; }
+__host__ __device__ inline int64_t a_pack_doubles(int n_s, int n_pad) {
+    return w_pack_doubles(n_s, n_pad) + r_pack_doubles(n_s, n_pad);
+}
 
 // index of element (c in 0..15, k) inside a fragment-ordered strip
 __device__ __forceinline__ int frag_index(int c, int k) {
@@ -41,8 +44,8 @@ struct GpConst {
     double outputscale[NS];
     double noise[NS];
     const double* x_train;
-    const double* w_pack;
-    const double* r_pack;
+    const double* a_pack;    // W_d fragments, then (at pair offset NS * w_pairs_per_output) the mean/Jacobian rows
+    const int4* stage_tab;   // [nw] headers {stage count}, then [nw][stage_cap] stage descriptors
     int n_train;
     int n_pad;
     int stage_cap;  // gp_stage_cap(NS, n_pad, waves per workgroup)
@@ -56,30 +59,27 @@ struct GpTileLds {
     double* mj;     // [NS][16 rows][16]  mean / Jacobian rows
     double* part;   // [NW][NS][16]       per-wave partial sums of squares
     double* zs;     // [16][D]            query points
-    int4* stages;   // [NW][stage_cap]    static MFMA operand stream of each wave (built once per kernel)
-    int* nstages;   // [NW]
-    __device__ double* carve(double* base, int n_train, int n_pad, int nw, int stage_cap) {
+    __device__ double* carve(double* base, int n_train, int n_pad, int nw) {
         xs = base;
         kfrag = xs + ((n_train * D + 1) & ~1);
         mj = kfrag + (size_t)NS * n_pad * 16;
         part = mj + NS * 256;
         zs = part + (size_t)nw * NS * 16;
-        stages = reinterpret_cast<int4*>(zs + 16 * D);
-        nstages = reinterpret_cast<int*>(stages + (size_t)nw * stage_cap);
-        return zs + 16 * D + 2 * (size_t)nw * stage_cap + ((nw + 1) >> 1);
+        return zs + 16 * D;
     }
 };
 
 // MFMA work decomposition shared by host (LDS sizing) and device (stream construction).
 //   task j <  NS : the mean/Jacobian rows of output j            (n_pad / 8 fragment pairs)
 //   task j >= NS : row-block rb of W_d, rb descending             (2 (rb + 1) pairs)
-// snake-assigned to the waves by cost; every task is cut into stages of 4 pairs (a 2-pair tail when needed).
+// snake-assigned to the waves by cost; every task is cut into stages of 2 pairs (4 MFMAs; pair counts are even).
 __host__ __device__ inline int gp_task_of(int round, int wave, int nw) {
     return round * nw + ((round & 1) ? (nw - 1 - wave) : wave);
 }
 __host__ __device__ inline int gp_task_pairs(int j, int ns, int nrb) {
     return j < ns ? 2 * nrb : 2 * (nrb - (j - ns) / ns);
 }
+constexpr int kStagePad = 8;  // dummy descriptors behind a wave's stream: prefetches past the end stay in bounds
 inline int gp_stage_cap(int ns, int n_pad, int nw) {
     const int nrb = n_pad >> 4, ntask = ns * (nrb + 1), rounds = (ntask + nw - 1) / nw;
     int cap = 0;
@@ -87,16 +87,17 @@ inline int gp_stage_cap(int ns, int n_pad, int nw) {
         int n = 0;
         for (int r = 0; r < rounds; ++r) {
             const int j = gp_task_of(r, w, nw);
-            if (j < ntask) n += (gp_task_pairs(j, ns, nrb) + 3) / 4;
+            if (j < ntask) n += gp_task_pairs(j, ns, nrb) / 2;
         }
         cap = n > cap ? n : cap;
     }
-    return (cap + 1) & ~1;  // even: the stream is consumed two stages at a time
+    return cap + kStagePad;
 }
 
+inline int64_t gp_stage_tab_ints(int ns, int n_pad, int nw) { return 4 * (int64_t)nw * (1 + gp_stage_cap(ns, n_pad, nw)); }
+
 inline size_t gp_tile_lds_doubles(int ns, int d, int n_train, int n_pad, int nw) {
-    return (size_t)((n_train * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d +
-           2 * (size_t)nw * gp_stage_cap(ns, n_pad, nw) + ((nw + 1) >> 1);
+    return (size_t)((n_train * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d;
 }
 
 template <int NS, int D>
@@ -138,27 +139,32 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
 
 // Phase 2: the triangular products on the matrix cores.
 //
-// A wave's share of the work never changes, so it is written to LDS once per kernel (gp_build_stages) as a flat
-// stream of stage descriptors
-//     int4 { x: pair offset into w_pack (r_pack when extra), y: v2d offset into kfrag, z: output d, w: flags }
-// flags: 1 = four pairs (else two), 2 = last stage of its task, 4 = mean/Jacobian rows ("extra"), 8 = valid.
-// One stage = up to 4 fragment pairs = 8 MFMAs = 512 matrix-core cycles.  The stream is consumed two stages at a
-// time with two register sets, so the A fragments (global: L2-resident W) and B fragments (LDS: Kstar) of stage
-// i + 1 are in flight while stage i computes -- across task boundaries too.
-constexpr int kStageFour = 1, kStageLast = 2, kStageExtra = 4, kStageValid = 8;
+// A wave's share of the work is static, so sx_gp_pack writes it once (build_stage_tab_kernel) to global memory as a
+// flat stream of stage descriptors
+//     int4 { x: pair offset into a_pack, y: v2d offset into kfrag, z: output d, w: flags }
+// flags: 2 = last stage of its task, 4 = mean/Jacobian rows ("extra").
+// One stage = 2 fragment pairs = 4 MFMAs = 256 matrix-core cycles.  Four register sets rotate, so the A fragments
+// (global: L2-resident W) and B fragments (LDS: Kstar) of stages i+1 .. i+3 are in flight while stage i computes --
+// across task boundaries too.
+//
+// On gfx950 the f64 MFMA does NOT hide VALU work of its own wave (measured, tools/mfma_probe2.hip: every VALU
+// instruction placed between two v_mfma_f64_16x16x4 costs ~8 cycles, v_readfirstlane ~28), so the stream is driven
+// by the SCALAR unit: descriptors arrive by s_load (uniform global loads), the A address is an SGPR base + a constant
+// per-lane offset, and the only vector instruction per stage besides loads and MFMAs is the B address add.
+constexpr int kStageLast = 2, kStageExtra = 4;
 
-template <int NS, int D>
-__device__ __forceinline__ void gp_build_stages(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int wave, int nw,
-                                                int lane) {
-    const int nrb = gc.n_pad >> 4;
-    const int ntask = NS * (nrb + 1);
+// one workgroup of nw waves; tab = [nw] headers, then [nw][stage_cap] descriptors
+__device__ __forceinline__ void gp_build_stage_tab(int4* tab, int ns, int n_pad, int nw, int stage_cap, int wave,
+                                                   int lane) {
+    const int nrb = n_pad >> 4;
+    const int ntask = ns * (nrb + 1);
     const int wpo = (int)w_pairs_per_output(nrb);
     // lane = round; (host guarantees rounds <= 64)
     const int rounds = (ntask + nw - 1) / nw;
     const int j = gp_task_of(lane, wave, nw);
     const bool has = lane < rounds && j < ntask;
-    const int npairs = has ? gp_task_pairs(j, NS, nrb) : 0;
-    const int mine = (npairs + 3) >> 2;
+    const int npairs = has ? gp_task_pairs(j, ns, nrb) : 0;
+    const int mine = npairs >> 1;
     int incl = mine;  // inclusive scan over the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -166,95 +172,100 @@ __device__ __forceinline__ void gp_build_stages(const GpConst<NS, D>& gc, GpTile
         if (lane >= off) incl += v;
     }
     const int total = __shfl(incl, 63);
-    int4* out = lds.stages + (size_t)wave * gc.stage_cap;
+    int4* out = tab + nw + (size_t)wave * stage_cap;
     if (has) {
         int d, a0, extra;
-        if (j < NS) {
+        if (j < ns) {
             d = j;
-            a0 = j * (gc.n_pad >> 3);
+            a0 = ns * wpo + j * (n_pad >> 3);  // the mean/Jacobian rows follow the W fragments in a_pack
             extra = kStageExtra;
         } else {
-            const int jj = j - NS;
-            const int rb = nrb - 1 - jj / NS;
-            d = jj % NS;
+            const int jj = j - ns;
+            const int rb = nrb - 1 - jj / ns;
+            d = jj % ns;
             a0 = d * wpo + rb * (rb + 1);
             extra = 0;
         }
         int pos = incl - mine;
-        for (int q = 0; q < npairs; q += 4, ++pos) {
-            const int fl = kStageValid | extra | ((npairs - q >= 4) ? kStageFour : 0) | ((q + 4 >= npairs) ? kStageLast : 0);
-            out[pos] = int4{a0 + q, d * gc.n_pad * 8 + q * 64, d, fl};
-        }
+        for (int q = 0; q < npairs; q += 2, ++pos)
+            out[pos] = int4{a0 + q, d * n_pad * 8 + q * 64, d, extra | ((q + 2 >= npairs) ? kStageLast : 0)};
     }
-    if (lane == 0) {
-        if (total & 1) out[total] = int4{0, 0, 0, 0};  // pad to an even count with an invalid stage
-        lds.nstages[wave] = (total + 1) & ~1;
-    }
+    // dummy descriptors (valid addresses, never computed on) behind the stream
+    if (lane < kStagePad) out[total + lane] = int4{0, 0, 0, 0};
+    if (lane == 0) tab[wave] = int4{total, 0, 0, 0};
 }
 
 struct MfmaStage {
-    v2d a[4];
-    v2d b[4];
+    v2d a0, a1, b0, b1;
     int z, w;
 };
 
+#define SX_PIN() __builtin_amdgcn_sched_barrier(0)
+
 template <int NS, int D>
-__device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int wave, int nw,
-                                              int lane) {
+__device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const int4* __restrict__ stage_tab,
+                                              GpTileLds<NS, D>& lds, int wave, int nw, int lane) {
     double ssq[NS];
 #pragma unroll
     for (int d = 0; d < NS; ++d) ssq[d] = 0.0;
 
-    const int4* stages = lds.stages + (size_t)wave * gc.stage_cap;
-    const int nst = __builtin_amdgcn_readfirstlane(lds.nstages[wave]);
-    const v2d* wbase = reinterpret_cast<const v2d*>(gc.w_pack) + lane;
-    const v2d* rbase = reinterpret_cast<const v2d*>(gc.r_pack) + lane;
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    // stage_tab is a __restrict__ kernel argument of its own: the loads below are provably unclobbered and uniform,
+    // which is what lets the compiler issue them as s_load
+    const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * gc.stage_cap;
+    const int nst = stage_tab[swave].x;
+    const char* abase = reinterpret_cast<const char*>(gc.a_pack);
+    const unsigned lane16 = (unsigned)lane * 16u;
     const v2d* kbase = reinterpret_cast<const v2d*>(lds.kfrag) + lane;
 
-    // descriptors are wave-uniform: SGPRs, scalar branches.  Always four loads per operand: a 2-pair stage re-reads
-    // its second pair (never consumed) instead of branching around loads.
-    auto issue = [&](MfmaStage& st, int i) {
-        const int4 t = stages[i];
-        const int x = __builtin_amdgcn_readfirstlane(t.x), y = __builtin_amdgcn_readfirstlane(t.y);
-        st.z = __builtin_amdgcn_readfirstlane(t.z);
-        st.w = __builtin_amdgcn_readfirstlane(t.w);
-        const v2d* ap = ((st.w & kStageExtra) ? rbase : wbase) + (int64_t)x * 64;
-        const v2d* bp = kbase + y;
-        const int i2 = (st.w & kStageFour) ? 128 : 64, i3 = (st.w & kStageFour) ? 192 : 64;
-        st.a[0] = ap[0];
-        st.a[1] = ap[64];
-        st.a[2] = ap[i2];
-        st.a[3] = ap[i3];
-        st.b[0] = bp[0];
-        st.b[1] = bp[64];
-        st.b[2] = bp[i2];
-        st.b[3] = bp[i3];
+    // `desc` always holds the descriptor of the next stage to be issued, fetched one issue earlier.
+    int4 desc = stages[0];
+    const char* ap;
+    const v2d* bp;
+    auto decode = [&](MfmaStage& st, int inext) {
+        ap = abase + (int64_t)desc.x * 1024;   // SGPR arithmetic
+        bp = kbase + desc.y;                   // the one VALU op of a stage
+        st.z = desc.z;
+        st.w = desc.w;
+        desc = stages[inext + 1];
+    };
+    auto load_a = [&](int byte_off) -> v2d { return *reinterpret_cast<const v2d*>(ap + byte_off + lane16); };
+    auto issue = [&](MfmaStage& st, int i) {  // prologue form: no computing stage in front
+        decode(st, i);
+        st.a0 = load_a(0);
+        st.a1 = load_a(1024);
+        st.b0 = bp[0];
+        st.b1 = bp[64];
     };
 
     v4d acc0 = {0.0, 0.0, 0.0, 0.0};
     v4d acc1 = {0.0, 0.0, 0.0, 0.0};
-    auto compute = [&](const MfmaStage& st) {
-        if (!(st.w & kStageValid)) return;
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a[0].x, st.b[0].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a[0].y, st.b[0].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a[1].x, st.b[1].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a[1].y, st.b[1].y, acc1, 0, 0, 0);
-        if (st.w & kStageFour) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a[2].x, st.b[2].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a[2].y, st.b[2].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a[3].x, st.b[3].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(st.a[3].y, st.b[3].y, acc1, 0, 0, 0);
-        }
-        if (st.w & kStageLast) {
+    // compute stage `cur` while putting stage `inext` in flight into `nx`
+    auto step = [&](const MfmaStage& cur, MfmaStage& nx, int inext) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a0.x, cur.b0.x, acc0, 0, 0, 0);
+        SX_PIN();
+        decode(nx, inext);
+        nx.a0 = load_a(0);
+        nx.a1 = load_a(1024);
+        SX_PIN();
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a0.y, cur.b0.y, acc1, 0, 0, 0);
+        SX_PIN();
+        nx.b0 = bp[0];
+        nx.b1 = bp[64];
+        SX_PIN();
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.x, cur.b1.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.y, cur.b1.y, acc1, 0, 0, 0);
+        SX_PIN();
+        if (cur.w & kStageLast) {
             const v4d t = acc0 + acc1;
-            if (st.w & kStageExtra) {
+            if (cur.w & kStageExtra) {
                 // row (lane >> 4) + 4 r of the 16 extra rows, column = query point lane & 15
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lds.mj[st.z * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = t[r];
+                for (int r = 0; r < 4; ++r) lds.mj[cur.z * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = t[r];
             } else {
                 const double s = t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
 #pragma unroll
-                for (int dd = 0; dd < NS; ++dd) ssq[dd] += (st.z == dd) ? s : 0.0;
+                for (int dd = 0; dd < NS; ++dd) ssq[dd] += (cur.z == dd) ? s : 0.0;
             }
             acc0 = v4d{0.0, 0.0, 0.0, 0.0};
             acc1 = v4d{0.0, 0.0, 0.0, 0.0};
@@ -262,13 +273,25 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, GpTileLd
     };
 
     if (nst > 0) {
-        MfmaStage sx, sy;
-        issue(sx, 0);
-        for (int i = 0; i < nst; i += 2) {
-            issue(sy, i + 1);
-            compute(sx);
-            if (i + 2 < nst) issue(sx, i + 2);
-            compute(sy);
+        MfmaStage s0, s1, s2, s3;
+        issue(s0, 0);
+        issue(s1, 1);
+        issue(s2, 2);
+        // steady state without conditional paths, so that the compiler's counted s_waitcnt keep all three
+        // prefetched stages in flight; the 1-3 leftover stages are peeled off behind it
+        int i = 0;
+        for (; i + 4 <= nst; i += 4) {
+            step(s0, s3, i + 3);
+            step(s1, s0, i + 4);
+            step(s2, s1, i + 5);
+            step(s3, s2, i + 6);
+        }
+        if (i < nst) {
+            step(s0, s3, i + 3);
+            if (i + 1 < nst) {
+                step(s1, s0, i + 4);
+                if (i + 2 < nst) step(s2, s1, i + 5);
+            }
         }
     }
 #pragma unroll

@@ -11,8 +11,11 @@
 
 namespace sx {
 
-constexpr int kRolloutThreads = 256;  // 4 waves: one per SIMD of the CU that owns the 16-particle tile
-constexpr int kPredictThreads = 256;
+#ifndef SX_ROLLOUT_THREADS
+#define SX_ROLLOUT_THREADS (64 * SX_WAVES)
+#endif
+constexpr int kRolloutThreads = SX_ROLLOUT_THREADS;  // waves of the CU that owns the 16-particle tile
+constexpr int kPredictThreads = 64 * SX_WAVES;
 
 // ---------------------------------------------------------------------------------------------------------------
 // sx_gp_pack: W_d / alpha_d -> fragment order
@@ -70,22 +73,27 @@ __global__ void pack_r_kernel(const double* __restrict__ alpha, const double* __
     }
 }
 
+__global__ void build_stage_tab_kernel(int4* tab, int ns, int n_pad, int nw, int stage_cap) {
+    gp_build_stage_tab(tab, ns, n_pad, nw, stage_cap, threadIdx.x >> 6, threadIdx.x & 63);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // sx_gp_predict: one 16-point tile per workgroup
 // ---------------------------------------------------------------------------------------------------------------
 template <int NS, int NU>
-__global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS, NS + NU> gc, const double* __restrict__ z,
-                                                                     int P, double* __restrict__ mean,
-                                                                     double* __restrict__ var, double* __restrict__ jac) {
+__global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS, NS + NU> gc,
+                                                                     const int4* __restrict__ stage_tab,
+                                                                     const double* __restrict__ z, int P,
+                                                                     double* __restrict__ mean, double* __restrict__ var,
+                                                                     double* __restrict__ jac) {
     constexpr int D = NS + NU;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpTileLds<NS, D> lds;
     const int nw = blockDim.x >> 6;
-    lds.carve(smem, gc.n_train, gc.n_pad, nw, gc.stage_cap);
+    lds.carve(smem, gc.n_train, gc.n_pad, nw);
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     gp_load_xs(gc, lds);
-    gp_build_stages(gc, lds, wave, nw, lane);
     for (int tile = blockIdx.x; tile * SX_TILE < P; tile += gridDim.x) {
         const int g0 = tile * SX_TILE;
         if (tid < SX_TILE * D) {
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
         __syncthreads();
         gp_kstar_phase(gc, lds);
         __syncthreads();
-        gp_mfma_phase(gc, lds, wave, nw, lane);
+        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane);
         __syncthreads();
         if (tid < SX_TILE && g0 + tid < P) {
             double zz[D], m[NS], v[NS], jc[NS][D];
@@ -195,6 +203,18 @@ __global__ void polytope_kernel(PolyArgs<NS> pa, int P, double c_safety, const d
 // ---------------------------------------------------------------------------------------------------------------
 // sx_cem_rollout: the fused H-step particle rollout.  One workgroup = 16 particles of one problem for all H steps.
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef SX_STAMPS
+// Diagnostic build only (tools/phase_stamps.py): per-workgroup cycle sums of the three phases of a step.
+__device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
 struct RolloutPtrs {
     const double* x0;
     const double* q0;
@@ -211,14 +231,16 @@ struct RolloutPtrs {
 };
 
 template <int NS, int NU>
-__global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc,
+__global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS, NS + NU> gc,
+                                                                      const int4* __restrict__ stage_tab,
+                                                                      ReachConst<NS, NU> rc,
                                                                       CostConst<SX_MAX_M, NS, NU> cc, RolloutPtrs rp) {
     constexpr int D = NS + NU;
     constexpr int S = NS + NS * NS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpTileLds<NS, D> lds;
     const int nw = blockDim.x >> 6;
-    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw, gc.stage_cap);  // [16][H][NU]
+    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw);  // [16][H][NU]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int H = rp.H;
@@ -227,7 +249,6 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     const int c0 = (blockIdx.x - e * tiles_per_problem) * SX_TILE;  // first particle of the tile within problem e
 
     gp_load_xs(gc, lds);
-    gp_build_stages(gc, lds, wave, nw, lane);
     // sample (or load) this tile's action sequences: a = mean + std * eps
     for (int i = tid; i < SX_TILE * H * NU; i += blockDim.x) {
         const int c = i / (H * NU);
@@ -268,11 +289,29 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     }
     __syncthreads();
 
+#ifdef SX_STAMPS
+    unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0, c_e = 0, c_eb = 0;
+#endif
     for (int t = 0; t < H; ++t) {
+#ifdef SX_STAMPS
+        const unsigned long long t0 = stamp();
+#endif
         gp_kstar_phase(gc, lds);
+#ifdef SX_STAMPS
+        const unsigned long long t1 = stamp();
+#endif
         __syncthreads();
-        gp_mfma_phase(gc, lds, wave, nw, lane);
+#ifdef SX_STAMPS
+        const unsigned long long t2 = stamp();
+#endif
+        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane);
+#ifdef SX_STAMPS
+        const unsigned long long t3 = stamp();
+#endif
         __syncthreads();
+#ifdef SX_STAMPS
+        const unsigned long long t4 = stamp();
+#endif
         if (owner) {
             double z[D], u[NU], mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
 #pragma unroll
@@ -326,8 +365,21 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
                 for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
             }
         }
+#ifdef SX_STAMPS
+        const unsigned long long t5 = stamp();
+#endif
         __syncthreads();
+#ifdef SX_STAMPS
+        const unsigned long long t6 = stamp();
+        c_k += t1 - t0; c_kb += t2 - t1; c_m += t3 - t2; c_mb += t4 - t3; c_e += t5 - t4; c_eb += t6 - t5;
+#endif
     }
+#ifdef SX_STAMPS
+    if (g_stamp_buf && lane == 0) {
+        unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * nw + wave) * 8;
+        o[0] = c_k; o[1] = c_kb; o[2] = c_m; o[3] = c_mb; o[4] = c_e; o[5] = c_eb;
+    }
+#endif
     if (valid) {
         const int64_t g = (int64_t)e * rp.P + c0 + tid;
         rp.obj_cost[g] = obj;
@@ -564,8 +616,8 @@ static GpConst<NS, NS + NU> make_gp_const(const sx_gp_model* m, int nw) {
         gc.noise[d] = m->noise[d];
     }
     gc.x_train = m->x_train;
-    gc.w_pack = m->w_pack;
-    gc.r_pack = m->r_pack;
+    gc.a_pack = m->a_pack;
+    gc.stage_tab = reinterpret_cast<const int4*>(m->stage_tab);
     gc.n_train = m->n_train;
     gc.n_pad = m->n_pad;
     gc.stage_cap = gp_stage_cap(NS, m->n_pad, nw);
@@ -661,8 +713,8 @@ static int launch_predict(const sx_gp_model* m, const double* z, int P, double* 
     if (int rc = allow_lds(gp_predict_kernel<NS, NU>, lds)) return rc;
     const int tiles = (P + SX_TILE - 1) / SX_TILE;
     const int grid = tiles < 4096 ? tiles : 4096;
-    hipLaunchKernelGGL((gp_predict_kernel<NS, NU>), dim3(grid), dim3(kPredictThreads), lds, stream, gc, z, P, mean, var,
-                       jac);
+    hipLaunchKernelGGL((gp_predict_kernel<NS, NU>), dim3(grid), dim3(kPredictThreads), lds, stream, gc, gc.stage_tab, z, P,
+                       mean, var, jac);
     return check_launch();
 }
 
@@ -707,8 +759,8 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
         (gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) + (size_t)SX_TILE * rp.H * NU) * sizeof(double);
     if (int r = allow_lds(cem_rollout_kernel<NS, NU>, lds)) return r;
     const int tiles = (rp.P + SX_TILE - 1) / SX_TILE;
-    hipLaunchKernelGGL((cem_rollout_kernel<NS, NU>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc, rc, cc,
-                       rp);
+    hipLaunchKernelGGL((cem_rollout_kernel<NS, NU>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc,
+                       gc.stage_tab, rc, cc, rp);
     return check_launch();
 }
 
@@ -730,18 +782,24 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
 
 extern "C" {
 
+#ifdef SX_STAMPS
+int sx_debug_set_stamps(unsigned long long* dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(sx::g_stamp_buf), &dev_buf, sizeof(dev_buf)) == hipSuccess ? SX_OK : SX_ERR_LAUNCH;
+}
+#endif
+
 const char* sx_version(void) { return "sxamd 0.1 gfx950"; }
 
-int sx_gp_pack_sizes(int n_s, int n_train, int64_t* w_doubles, int64_t* r_doubles) {
+int sx_gp_pack_sizes(int n_s, int n_train, int64_t* a_doubles, int64_t* tab_ints) {
     if (n_s <= 0 || n_s > SX_MAX_NS || n_train <= 0) return SX_ERR_ARG;
     const int n_pad = (n_train + 15) / 16 * 16;
-    if (w_doubles) *w_doubles = sx::w_pack_doubles(n_s, n_pad);
-    if (r_doubles) *r_doubles = sx::r_pack_doubles(n_s, n_pad);
+    if (a_doubles) *a_doubles = sx::a_pack_doubles(n_s, n_pad);
+    if (tab_ints) *tab_ints = sx::gp_stage_tab_ints(n_s, n_pad, SX_WAVES);
     return SX_OK;
 }
 
 int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void* stream) {
-    if (!model || !linv || !alpha || !model->x_train || !model->w_pack || !model->r_pack) return SX_ERR_ARG;
+    if (!model || !linv || !alpha || !model->x_train || !model->a_pack || !model->stage_tab) return SX_ERR_ARG;
     if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)
         return SX_ERR_ARG;
     model->n_pad = (model->n_train + 15) / 16 * 16;
@@ -750,8 +808,9 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
     const int64_t wt = sx::w_pack_doubles(model->n_s, model->n_pad);
     int grid = (int)((wt + 255) / 256);
     if (grid > 8192) grid = 8192;
+    if ((model->n_s * ((model->n_pad >> 4) + 1) + SX_WAVES - 1) / SX_WAVES > 64) return SX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(sx::pack_w_kernel, dim3(grid), dim3(256), 0, s, linv, model->n_s, model->n_train, model->n_pad,
-                       const_cast<double*>(model->w_pack));
+                       const_cast<double*>(model->a_pack));
     sx::PackRArgs<SX_MAX_NS, SX_MAX_D> args;
     std::memset(&args, 0, sizeof(args));
     for (int i = 0; i < model->n_s * D; ++i) args.inv_ls2[i] = model->inv_ls2[i];
@@ -759,7 +818,10 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
     grid = (int)((rt + 255) / 256);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(sx::pack_r_kernel, dim3(grid), dim3(256), 0, s, alpha, model->x_train, args, model->n_s, D,
-                       model->n_train, model->n_pad, const_cast<double*>(model->r_pack));
+                       model->n_train, model->n_pad, const_cast<double*>(model->a_pack) + wt);
+    hipLaunchKernelGGL(sx::build_stage_tab_kernel, dim3(1), dim3(64 * SX_WAVES), 0, s,
+                       reinterpret_cast<int4*>(const_cast<int32_t*>(model->stage_tab)), model->n_s, model->n_pad,
+                       SX_WAVES, sx::gp_stage_cap(model->n_s, model->n_pad, SX_WAVES));
     return sx::check_launch();
 }
 

@@ -107,19 +107,19 @@ class GpCemSSM(CemSSM):
         linv = torch.linalg.solve_triangular(chol, eye, upper=False).contiguous()
         alpha = torch.cholesky_solve(y.t().unsqueeze(2), chol).squeeze(2).contiguous()  # [n_s x N]
 
-        w_n, r_n = ctypes.c_int64(), ctypes.c_int64()
-        _lib.check(lib.sx_gp_pack_sizes(n_s, n, ctypes.byref(w_n), ctypes.byref(r_n)), 'sx_gp_pack_sizes')
-        w_pack = torch.empty(w_n.value, dtype=torch.float64, device=dev)
-        r_pack = torch.empty(r_n.value, dtype=torch.float64, device=dev)
+        a_n, t_n = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.sx_gp_pack_sizes(n_s, n, ctypes.byref(a_n), ctypes.byref(t_n)), 'sx_gp_pack_sizes')
+        a_pack = torch.empty(a_n.value, dtype=torch.float64, device=dev)
+        stage_tab = torch.empty(t_n.value, dtype=torch.int32, device=dev)
         m = _lib.SxGpModel()
         m.n_s, m.n_u, m.n_train = n_s, n_u, n
         _lib.fill(m.inv_ls2, (1.0 / self.lengthscale ** 2).numpy())
         _lib.fill(m.outputscale, self.outputscale.numpy())
         _lib.fill(m.noise, self.noise.numpy())
-        m.x_train, m.w_pack, m.r_pack = x.data_ptr(), w_pack.data_ptr(), r_pack.data_ptr()
+        m.x_train, m.a_pack, m.stage_tab = x.data_ptr(), a_pack.data_ptr(), stage_tab.data_ptr()
         _lib.check(lib.sx_gp_pack(ctypes.byref(m), _lib.ptr(linv), _lib.ptr(alpha), _lib.stream_ptr(dev)), 'sx_gp_pack')
         self._model = m
-        self._buffers = (x, w_pack, r_pack, linv, alpha)
+        self._buffers = (x, a_pack, stage_tab, linv, alpha)
 
     @property
     def device_model(self) -> _lib.SxGpModel:

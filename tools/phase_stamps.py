@@ -1,0 +1,40 @@
+"""Diagnostic: where does a rollout step spend its cycles?  Needs the -DSX_STAMPS build:
+
+    SX_OUT=libsxamd_stamps.so SX_EXTRA_FLAGS=-DSX_STAMPS safe_exploration_amd/csrc/build.sh
+    SX_LIB=$PWD/safe_exploration_amd/csrc/libsxamd_stamps.so python tools/phase_stamps.py
+
+Reads SHARES only (the stamp build forbids overlaps the product build has; never quote its run time).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from safe_exploration_amd import _lib, problems  # noqa: E402
+from safe_exploration_amd.cem_mpc import cem_rollout  # noqa: E402
+
+P, H = int(os.environ.get('P', 4096)), int(os.environ.get('H', 15))
+spec = problems.pendulum(n_train=int(os.environ.get('N', 200)))
+ssm, env = problems.build(spec, 'cuda:0')
+dev = torch.device('cuda:0')
+nwg, nw = (P + 15) // 16, int(os.environ.get('NW', 4))
+buf = torch.zeros((nwg * nw, 8), dtype=torch.int64, device=dev)
+lib = _lib.lib()
+lib.sx_debug_set_stamps.argtypes = [ctypes.c_void_p]
+assert lib.sx_debug_set_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
+x0 = torch.tensor([[0.02, -0.03]], dtype=torch.float64, device=dev)
+mean = torch.zeros((1, H, 1), dtype=torch.float64, device=dev)
+std = torch.full((1, H, 1), 0.1, dtype=torch.float64, device=dev)
+noise = torch.randn((1, P, H, 1), dtype=torch.float64, device=dev)
+for _ in range(3):
+    cem_rollout(ssm, env, x0, H, mean=mean, std=std, noise=noise)
+torch.cuda.synchronize()
+s = buf.cpu().numpy().reshape(nwg, nw, 8)[:, :, :6].astype(np.float64) / H
+names = ['kstar', 'kstar->barrier', 'mfma', 'mfma->barrier', 'epilogue', 'epilogue->barrier']
+print(f'cycles per step (median over {nwg} workgroups), per wave:')
+for w in range(nw):
+    med = np.median(s[:, w, :], axis=0)
+    print(f'  wave {w}: ' + '  '.join(f'{n}={v:8.0f}' for n, v in zip(names, med)) + f'   total={med.sum():8.0f}')

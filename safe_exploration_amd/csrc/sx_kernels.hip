@@ -389,11 +389,19 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// sx_cem_rank_refit: one workgroup per problem.  128-bit radix select (con, obj) + index tie-break, then a bitonic
-// sort of the k survivors, then the refit.
+// sx_cem_rank_refit: one workgroup (16 waves) per problem.
+//   1. every thread keeps its candidates' 128-bit keys (con, obj) in registers: element i lives in slot i / 1024 of
+//      thread i % 1024, so (slot, thread) order is index order;
+//   2. MSB-first radix select of the k-th key, 8 bits per pass: wave-aggregated LDS histogram (one atomic per wave when
+//      all lanes agree -- the common case in the high bytes), bin scan by one wave, early exit as soon as the bin
+//      holding the k-th key is wholly selected;
+//   3. ballot compaction in index order (ties broken by the lower index), bitonic sort of the k survivors in LDS;
+//   4. refit: mean / unbiased std over the elites, rows spread over the whole workgroup.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRankThreads = 1024;
+constexpr int kRankWaves = kRankThreads / 64;
 constexpr int kRankMaxK = 2048;
+constexpr int kRankSlots = 16;  // candidates per thread held in registers: P <= 16384
 
 __device__ __forceinline__ unsigned long long sortable_key(double x) {
     if (x != x) return ~0ull;  // NaN last
@@ -416,126 +424,130 @@ struct RankArgs {
     int* best_ok;
 };
 
+template <int SLOTS>
 __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long sel_hi[kRankMaxK], sel_lo[kRankMaxK];
     __shared__ int sel_idx[kRankMaxK];
-    __shared__ unsigned long long pref_hi, pref_lo;
-    __shared__ int need, n_less, n_tie_taken, sh_digit;
-    __shared__ int scan[kRankThreads];
+    __shared__ double red[kRankThreads];
+    __shared__ double col_mean[256];
+    __shared__ int wave_cnt[kRankWaves][2];
+    __shared__ int sh_digit, sh_need, sh_done;
 
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int P = ra.P, k = ra.k;
     const double* con = ra.con + (long long)e * P * ra.cost_stride;
     const double* obj = ra.obj + (long long)e * P * ra.cost_stride;
     const double* act = ra.actions + (long long)e * P * ra.act_stride;
 
-    if (tid == 0) {
-        pref_hi = 0;
-        pref_lo = 0;
-        need = k;
+    unsigned long long kh[SLOTS], kl[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int i = s * kRankThreads + tid;
+        kh[s] = ~0ull;
+        kl[s] = ~0ull;
+        if (i < P) {
+            kh[s] = sortable_key(con[(long long)i * ra.cost_stride]);
+            kl[s] = sortable_key(obj[(long long)i * ra.cost_stride]);
+        }
     }
-    __syncthreads();
-    // MSB-first radix select of the k-th smallest 128-bit key (hi = con, lo = obj)
-    for (int pass = 0; pass < 16; ++pass) {
+
+    // ---- radix select ----
+    unsigned long long ph = 0, pl = 0;   // prefix of the k-th key found so far (uniform)
+    unsigned long long mh = 0, ml = 0;   // mask of the prefix bits
+    int need = k;                        // rank of the k-th key among the candidates matching the prefix
+    bool done = false;
+    for (int pass = 0; pass < 16 && !done; ++pass) {
         const int shift = 56 - 8 * (pass & 7);
         const bool in_hi = pass < 8;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        const unsigned long long ph = pref_hi, pl = pref_lo;
-        for (int i = tid; i < P; i += kRankThreads) {
-            const unsigned long long kh = sortable_key(con[(long long)i * ra.cost_stride]);
-            const unsigned long long kl = sortable_key(obj[(long long)i * ra.cost_stride]);
-            bool match;
-            unsigned int digit;
-            if (in_hi) {
-                const unsigned long long mask = (pass == 0) ? 0ull : (~0ull << (shift + 8));
-                match = (kh & mask) == (ph & mask);
-                digit = (unsigned int)(kh >> shift) & 255u;
-            } else {
-                const unsigned long long mask = (pass == 8) ? 0ull : (~0ull << (shift + 8));
-                match = (kh == ph) && ((kl & mask) == (pl & mask));
-                digit = (unsigned int)(kl >> shift) & 255u;
-            }
-            if (match) atomicAdd(&hist[digit], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int rem = need;
-            int dsel = 255;
-            for (int dgt = 0; dgt < 256; ++dgt) {
-                const int cnt = (int)hist[dgt];
-                if (rem <= cnt) {
-                    dsel = dgt;
-                    break;
-                }
-                rem -= cnt;
-            }
-            need = rem;
-            sh_digit = dsel;
-            if (in_hi)
-                pref_hi |= ((unsigned long long)dsel) << shift;
-            else
-                pref_lo |= ((unsigned long long)dsel) << shift;
-        }
-        __syncthreads();
-    }
-    // (pref_hi, pref_lo) is the key of the k-th candidate; `need` of the candidates with exactly that key are taken,
-    // lowest index first.  Compact in index order: strictly-less first, then ties.
-    const unsigned long long th = pref_hi, tl = pref_lo;
-    const int tie_quota = need;
-    if (tid == 0) {
-        n_less = 0;
-        n_tie_taken = 0;
-    }
-    __syncthreads();
-    for (int base = 0; base < P; base += kRankThreads) {
-        const int i = base + tid;
-        unsigned long long kh = 0, kl = 0;
-        int cls = 0;  // 1 = strictly less, 2 = tie
-        if (i < P) {
-            kh = sortable_key(con[(long long)i * ra.cost_stride]);
-            kl = sortable_key(obj[(long long)i * ra.cost_stride]);
-            if (kh < th || (kh == th && kl < tl))
-                cls = 1;
-            else if (kh == th && kl == tl)
-                cls = 2;
-        }
-        // block-wide exclusive scans (Hillis-Steele in LDS) for the two classes, packed as (ties << 16 | less)
-        scan[tid] = (cls == 1 ? 1 : 0) | (cls == 2 ? (1 << 16) : 0);
-        __syncthreads();
-        for (int off = 1; off < kRankThreads; off <<= 1) {
-            const int v = (tid >= off) ? scan[tid - off] : 0;
-            __syncthreads();
-            scan[tid] += v;
-            __syncthreads();
-        }
-        const int incl = scan[tid];
-        const int total = scan[kRankThreads - 1];
-        const int less_before = n_less, tie_before = n_tie_taken;
-        if (cls == 1) {
-            const int slot = less_before + (incl & 0xffff) - 1;
-            sel_hi[slot] = kh;
-            sel_lo[slot] = kl;
-            sel_idx[slot] = i;
-        } else if (cls == 2) {
-            const int tie_rank = tie_before + (incl >> 16) - 1;
-            if (tie_rank < tie_quota) {
-                const int slot = (k - tie_quota) + tie_rank;
-                sel_hi[slot] = kh;
-                sel_lo[slot] = kl;
-                sel_idx[slot] = i;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int i = s * kRankThreads + tid;
+            const bool match = (i < P) && ((kh[s] & mh) == ph) && ((kl[s] & ml) == pl);
+            const unsigned int digit = match ? (unsigned int)(((in_hi ? kh[s] : kl[s]) >> shift) & 255ull) : 0xffffffffu;
+            const unsigned int first = __builtin_amdgcn_readfirstlane(digit);
+            if (__all(digit == first)) {
+                if (first != 0xffffffffu && lane == 0) atomicAdd(&hist[first], 64u);
+            } else if (match) {
+                atomicAdd(&hist[digit], 1u);
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            n_less = less_before + (total & 0xffff);
-            n_tie_taken = tie_before + (total >> 16);
+        if (wave == 0) {
+            // lane l owns bins 4l .. 4l+3
+            const unsigned int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+            const int mine = (int)(c0 + c1 + c2 + c3);
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            const int before = incl - mine;
+            if (need > before && need <= incl) {
+                int rem = need - before;
+                int dsel = 4 * lane;
+                unsigned int cnt = c0;
+                if (rem > (int)c0) { rem -= c0; dsel++; cnt = c1;
+                    if (rem > (int)c1) { rem -= c1; dsel++; cnt = c2;
+                        if (rem > (int)c2) { rem -= c2; dsel++; cnt = c3; } } }
+                sh_digit = dsel;
+                sh_need = rem;
+                sh_done = (rem == (int)cnt) ? 1 : 0;  // the whole bin is selected: no need to look at lower digits
+            }
         }
         __syncthreads();
+        const unsigned long long dg = (unsigned long long)sh_digit << shift, mk = 255ull << shift;
+        if (in_hi) { ph |= dg; mh |= mk; } else { pl |= dg; ml |= mk; }
+        need = sh_need;
+        done = sh_done != 0;
     }
-    // bitonic sort of the k selected entries by (hi, lo, idx); pad to a power of two with +inf keys
+    // Candidates whose masked key is below the prefix are selected; of those equal to it, the first `need` in index
+    // order (all of them after an early exit).
+    const int n_less_total = k - need;
+    int base_less = 0, base_tie = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        if (s * kRankThreads >= P) break;
+        const int i = s * kRankThreads + tid;
+        const unsigned long long a_h = kh[s] & mh, a_l = kl[s] & ml;
+        const bool valid = i < P;
+        const bool less = valid && (a_h < ph || (a_h == ph && a_l < pl));
+        const bool tie = valid && a_h == ph && a_l == pl;
+        const unsigned long long bl = __ballot(less), bt = __ballot(tie);
+        if (lane == 0) {
+            wave_cnt[wave][0] = __popcll(bl);
+            wave_cnt[wave][1] = __popcll(bt);
+        }
+        __syncthreads();
+        int off_less = base_less, off_tie = base_tie, tot_less = 0, tot_tie = 0;
+#pragma unroll
+        for (int w = 0; w < kRankWaves; ++w) {
+            const int cl = wave_cnt[w][0], ct = wave_cnt[w][1];
+            if (w < wave) { off_less += cl; off_tie += ct; }
+            tot_less += cl;
+            tot_tie += ct;
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (less) {
+            const int slot = off_less + __popcll(bl & below);
+            sel_hi[slot] = kh[s]; sel_lo[slot] = kl[s]; sel_idx[slot] = i;
+        } else if (tie) {
+            const int r = off_tie + __popcll(bt & below);
+            if (r < need) {
+                const int slot = n_less_total + r;
+                sel_hi[slot] = kh[s]; sel_lo[slot] = kl[s]; sel_idx[slot] = i;
+            }
+        }
+        base_less += tot_less;
+        base_tie += tot_tie;
+        __syncthreads();
+    }
+    // ---- bitonic sort of the k selected entries by (hi, lo, idx); pad to a power of two with +inf keys ----
     int n2 = 1;
     while (n2 < k) n2 <<= 1;
     for (int i = k + tid; i < n2; i += kRankThreads) {
@@ -554,18 +566,14 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
                 const int ai = sel_idx[lo], bi = sel_idx[hi];
                 const bool a_gt_b = (ah > bh) || (ah == bh && (al > bl || (al == bl && ai > bi)));
                 if (a_gt_b == asc) {
-                    sel_hi[lo] = bh;
-                    sel_lo[lo] = bl;
-                    sel_idx[lo] = bi;
-                    sel_hi[hi] = ah;
-                    sel_lo[hi] = al;
-                    sel_idx[hi] = ai;
+                    sel_hi[lo] = bh; sel_lo[lo] = bl; sel_idx[lo] = bi;
+                    sel_hi[hi] = ah; sel_lo[hi] = al; sel_idx[hi] = ai;
                 }
             }
             __syncthreads();
         }
     }
-    // outputs
+    // ---- outputs ----
     const int L = ra.row_len;
     if (ra.elite_idx)
         for (int i = tid; i < k; i += kRankThreads) ra.elite_idx[(long long)e * k + i] = sel_idx[i];
@@ -584,23 +592,45 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             ra.elite_rows[((long long)e * k + r) * W + c] = v;
         }
     }
-    if (ra.mean) {
-        for (int c = tid; c < L; c += kRankThreads) {
-            double s = 0.0;
-            for (int r = 0; r < k; ++r) s += act[(long long)sel_idx[r] * ra.act_stride + c];
-            const double mu = s / k;
-            double ss = 0.0;
-            for (int r = 0; r < k; ++r) {
-                const double dv = act[(long long)sel_idx[r] * ra.act_stride + c] - mu;
-                ss += dv * dv;
-            }
-            ra.mean[(long long)e * L + c] = mu;
-            if (ra.std) ra.std[(long long)e * L + c] = (k > 1) ? sqrt(ss / (k - 1)) : 0.0;
-        }
-    }
     if (ra.best)
         for (int c = tid; c < L; c += kRankThreads) ra.best[(long long)e * L + c] = act[(long long)sel_idx[0] * ra.act_stride + c];
     if (ra.best_ok && tid == 0) ra.best_ok[e] = (con[(long long)sel_idx[0] * ra.cost_stride] == 0.0) ? 1 : 0;
+    if (ra.mean) {
+        // columns in chunks of up to 256; thread t sums rows t / Lc, t / Lc + R, ... of column t % Lc
+        for (int c0 = 0; c0 < L; c0 += 256) {
+            const int Lc = (L - c0) < 256 ? (L - c0) : 256;
+            const int R = kRankThreads / Lc;  // row groups
+            const int c = tid % Lc, r0 = tid / Lc;
+            const bool active = r0 < R;
+            double s = 0.0;
+            if (active)
+                for (int r = r0; r < k; r += R) s += act[(long long)sel_idx[r] * ra.act_stride + c0 + c];
+            red[tid] = s;
+            __syncthreads();
+            if (tid < Lc) {
+                double t = 0.0;
+                for (int g = 0; g < R; ++g) t += red[g * Lc + tid];
+                col_mean[tid] = t / k;
+            }
+            __syncthreads();
+            const double mu = col_mean[c];
+            double ss = 0.0;
+            if (active)
+                for (int r = r0; r < k; r += R) {
+                    const double dv = act[(long long)sel_idx[r] * ra.act_stride + c0 + c] - mu;
+                    ss += dv * dv;
+                }
+            red[tid] = ss;
+            __syncthreads();
+            if (tid < Lc) {
+                double t = 0.0;
+                for (int g = 0; g < R; ++g) t += red[g * Lc + tid];
+                ra.mean[(long long)e * L + c0 + tid] = col_mean[tid];
+                if (ra.std) ra.std[(long long)e * L + c0 + tid] = (k > 1) ? sqrt(t / (k - 1)) : 0.0;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -883,7 +913,14 @@ int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, 
     sx::RankArgs ra{P,      k,          row_len,    con_cost, obj_cost, (long long)cost_stride,
                     actions, (long long)act_stride, elite_idx, elite_rows, mean,     std,
                     best,   best_ok};
-    hipLaunchKernelGGL(sx::cem_rank_kernel, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
+    if (P > sx::kRankThreads * sx::kRankSlots) return SX_ERR_UNSUPPORTED;
+    const int slots = (P + sx::kRankThreads - 1) / sx::kRankThreads;
+    if (slots <= 4)
+        hipLaunchKernelGGL(sx::cem_rank_kernel<4>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
+    else if (slots <= 8)
+        hipLaunchKernelGGL(sx::cem_rank_kernel<8>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
+    else
+        hipLaunchKernelGGL(sx::cem_rank_kernel<sx::kRankSlots>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
     return sx::check_launch();
 }
 

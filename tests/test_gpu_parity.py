@@ -174,7 +174,8 @@ def test_fused_rollout_costs_vs_oracle(P, H, obj_mode):
     assert ref.status == 0 and int(r['status'].item()) == 0
 
 
-@pytest.mark.parametrize('P,k,L', [(16, 3, 4), (1000, 10, 15), (4096, 409, 15), (5000, 1, 30), (333, 333, 6)])
+@pytest.mark.parametrize('P,k,L', [(16, 3, 4), (1000, 10, 15), (4096, 409, 15), (5000, 1, 30), (333, 333, 6),
+                                   (12000, 64, 20), (16384, 2048, 300), (64, 64, 1)])
 def test_rank_refit_vs_oracle(P, k, L):
     from safe_exploration_amd.cem_mpc import cem_rank_refit
     rng = np.random.default_rng(P + k)

@@ -106,15 +106,17 @@ __device__ __forceinline__ void gp_load_xs(const GpConst<NS, D>& gc, GpTileLds<N
 }
 
 // Phase 1: Kstar_d[c][k] = s_d exp(-1/2 sum_j (z_cj - X_kj)^2 / l_dj^2) for the tile's 16 points, all k, all d.
-// blockDim.x must be a multiple of 16: a thread keeps the same query point c = tid & 15 for every k it visits.
+// Run by threads [first, blockDim.x), both multiples of 16: a thread keeps the same query point c = tid & 15 for every
+// k it visits (threads below `first` are busy elsewhere -- the rollout's wave 0 finishes the previous step meanwhile).
 template <int NS, int D>
-__device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds) {
+__device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int first = 0) {
+    if ((int)threadIdx.x < first) return;
     const int c = threadIdx.x & 15;
     double z[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) z[j] = lds.zs[c * D + j];
-    const int kstep = blockDim.x >> 4;
-    for (int k = threadIdx.x >> 4; k < gc.n_pad; k += kstep) {
+    const int kstep = ((int)blockDim.x - first) >> 4;
+    for (int k = ((int)threadIdx.x - first) >> 4; k < gc.n_pad; k += kstep) {
         const int fi = frag_index(c, k);
         if (k < gc.n_train) {
             double sq[D];

@@ -289,6 +289,80 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     }
     __syncthreads();
 
+    // Step t:   Kstar(t)  |sync|  MFMA(t)  |sync|  quick(t): p_{t+1} = mean + a p + b u  ->  zs  |sync|
+    // The rest of step t (variance, Jacobian, ellipsoid algebra, costs: ~4.5k cycles on 16 lanes) does not feed
+    // Kstar(t+1), so wave 0 runs it DURING Kstar(t+1) while waves 1..7 compute the kernel rows.
+    double pn[NS];  // p_{t+1} from quick(t), kept for finish(t)
+    auto quick = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            double s = lds.mj[i * 256 + tid];  // posterior mean of output i
+#pragma unroll
+            for (int j = 0; j < NS; ++j) s += rc.a[i * NS + j] * p[j];
+#pragma unroll
+            for (int cidx = 0; cidx < NU; ++cidx) s += rc.b[i * NU + cidx] * acts[(tid * H + t) * NU + cidx];
+            pn[i] = s;
+        }
+        if (t + 1 < H) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = pn[i];
+#pragma unroll
+            for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
+        }
+    };
+    auto finish = [&](int t) {
+        double z[D], u[NU], mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) z[j] = p[j];
+#pragma unroll
+        for (int cidx = 0; cidx < NU; ++cidx) {
+            u[cidx] = acts[(tid * H + t) * NU + cidx];
+            z[NS + cidx] = u[cidx];
+        }
+        int st_step = 0;
+        if (have_q) {
+            gp_collect<NS, D, true>(gc, lds, nw, tid, z, mean, var, jac);
+            reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st_step);
+        } else {
+            gp_collect<NS, D, false>(gc, lds, nw, tid, z, mean, var, jac);
+            reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st_step);
+        }
+        have_q = true;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) p1[i] = pn[i];  // exactly the centre the next GP query used
+        if (valid) st |= st_step;
+        // costs (safempc_cem.py:102-132,304-312; action constraint: test_safempc_cem.py:59-71)
+        obj += objective_cost<SX_MAX_M, NS, NU>(cc, p1, var);
+        bool uviol = false;
+#pragma unroll
+        for (int cidx = 0; cidx < NU; ++cidx) uviol = uviol || (u[cidx] < cc.u_min[cidx]) || (u[cidx] > cc.u_max[cidx]);
+        if (uviol) con += SX_ACTION_VIOLATION_COST;
+        if (cc.con_mode == SX_CON_ALL_STATES || t == H - 1) {
+            if (polytope_violated<SX_MAX_M, NS>(cc.h_mat, cc.h_vec, cc.m, 1.0, p1, Q1, nullptr))
+                con += SX_STATE_VIOLATION_COST;
+        }
+        const int64_t g = (int64_t)e * rp.P + c0 + tid;
+        if (valid && rp.traj) {
+            double* tr = rp.traj + (g * H + t) * S;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                tr[i] = p1[i];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) tr[NS + i * NS + j] = Q1[i][j];
+            }
+        }
+        if (valid && rp.sigma) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) rp.sigma[(g * H + t) * NS + i] = var[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            p[i] = p1[i];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) Q[i][j] = Q1[i][j];
+        }
+    };
+
 #ifdef SX_STAMPS
     unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0, c_e = 0, c_eb = 0;
 #endif
@@ -296,7 +370,13 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 #ifdef SX_STAMPS
         const unsigned long long t0 = stamp();
 #endif
-        gp_kstar_phase(gc, lds);
+        if (t == 0) {
+            gp_kstar_phase(gc, lds);
+        } else if (wave == 0) {
+            if (owner) finish(t - 1);
+        } else {
+            gp_kstar_phase(gc, lds, 64);
+        }
 #ifdef SX_STAMPS
         const unsigned long long t1 = stamp();
 #endif
@@ -312,59 +392,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 #ifdef SX_STAMPS
         const unsigned long long t4 = stamp();
 #endif
-        if (owner) {
-            double z[D], u[NU], mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
-#pragma unroll
-            for (int j = 0; j < D; ++j) z[j] = lds.zs[tid * D + j];
-#pragma unroll
-            for (int cidx = 0; cidx < NU; ++cidx) u[cidx] = z[NS + cidx];
-            int st_step = 0;
-            if (have_q) {
-                gp_collect<NS, D, true>(gc, lds, nw, tid, z, mean, var, jac);
-                reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st_step);
-            } else {
-                gp_collect<NS, D, false>(gc, lds, nw, tid, z, mean, var, jac);
-                reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st_step);
-            }
-            have_q = true;
-            if (valid) st |= st_step;
-            // costs (safempc_cem.py:102-132,304-312; action constraint: test_safempc_cem.py:59-71)
-            obj += objective_cost<SX_MAX_M, NS, NU>(cc, p1, var);
-            bool uviol = false;
-#pragma unroll
-            for (int cidx = 0; cidx < NU; ++cidx) uviol = uviol || (u[cidx] < cc.u_min[cidx]) || (u[cidx] > cc.u_max[cidx]);
-            if (uviol) con += SX_ACTION_VIOLATION_COST;
-            if (cc.con_mode == SX_CON_ALL_STATES || t == H - 1) {
-                if (polytope_violated<SX_MAX_M, NS>(cc.h_mat, cc.h_vec, cc.m, 1.0, p1, Q1, nullptr))
-                    con += SX_STATE_VIOLATION_COST;
-            }
-            const int64_t g = (int64_t)e * rp.P + c0 + tid;
-            if (valid && rp.traj) {
-                double* tr = rp.traj + (g * H + t) * S;
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    tr[i] = p1[i];
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) tr[NS + i * NS + j] = Q1[i][j];
-                }
-            }
-            if (valid && rp.sigma) {
-#pragma unroll
-                for (int i = 0; i < NS; ++i) rp.sigma[(g * H + t) * NS + i] = var[i];
-            }
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                p[i] = p1[i];
-#pragma unroll
-                for (int j = 0; j < NS; ++j) Q[i][j] = Q1[i][j];
-            }
-            if (t + 1 < H) {
-#pragma unroll
-                for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = p[i];
-#pragma unroll
-                for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
-            }
-        }
+        if (owner) quick(t);
 #ifdef SX_STAMPS
         const unsigned long long t5 = stamp();
 #endif
@@ -374,6 +402,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
         c_k += t1 - t0; c_kb += t2 - t1; c_m += t3 - t2; c_mb += t4 - t3; c_e += t5 - t4; c_eb += t6 - t5;
 #endif
     }
+    if (owner) finish(H - 1);
 #ifdef SX_STAMPS
     if (g_stamp_buf && lane == 0) {
         unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * nw + wave) * 8;

@@ -54,13 +54,13 @@ extern "C" {
 typedef struct sx_gp_model {
     int32_t n_s, n_u;            /* outputs, action dims; D = n_s + n_u inputs */
     int32_t n_train;             /* N */
-    int32_t n_pad;               /* 16 * ceil(N / 16) */
+    int32_t n_pad;               /* 16 * ceil((N + 1 + D) / 16): W_d padded, with room for the mean/Jacobian rows */
     double inv_ls2[SX_MAX_NS * SX_MAX_D];  /* [n_s x D] 1 / lengthscale^2 (ARD, per output) */
     double outputscale[SX_MAX_NS];
     double noise[SX_MAX_NS];     /* likelihood noise, added to the predictive variance (gp_ssm_cem.py:93) */
     const double* x_train;       /* dev [N x D] */
-    const double* a_pack;        /* dev, sx_gp_pack_sizes() doubles: W_d, then the rows alpha_d, alpha_d * X_j / l_dj^2,
-                                    in MFMA fragment order */
+    const double* a_pack;        /* dev, sx_gp_pack_sizes() doubles: W_d with the rows alpha_d, alpha_d * X_j / l_dj^2
+                                    appended, in MFMA fragment order */
     const int32_t* stage_tab;    /* dev, sx_gp_pack_sizes() int32: the static MFMA operand stream of every wave */
 } sx_gp_model;
 
@@ -94,7 +94,7 @@ const char* sx_version(void);
 #define SX_WAVES 8               /* waves per workgroup in the GP kernels (the stage table is laid out for it) */
 
 /* Sizes of sx_gp_model.a_pack (doubles) and sx_gp_model.stage_tab (int32). */
-int sx_gp_pack_sizes(int n_s, int n_train, int64_t* a_doubles, int64_t* tab_ints);
+int sx_gp_pack_sizes(int n_s, int n_u, int n_train, int64_t* a_doubles, int64_t* tab_ints);
 
 /* Lays W_d = L_d^-1 (dev [n_s x N x N], lower triangular) and alpha (dev [n_s x N]) out in fragment order.
  * model->{n_s,n_u,n_train,inv_ls2,x_train,a_pack,stage_tab} must be set; n_pad is filled in.

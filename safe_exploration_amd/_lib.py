@@ -43,7 +43,7 @@ class SxEnv(Structure):
 # name -> (restype, argtypes): exactly the entry points include/sx_amd.h declares
 SIGNATURES = {
     'sx_version': (c_char_p, []),
-    'sx_gp_pack_sizes': (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    'sx_gp_pack_sizes': (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     'sx_gp_pack': (c_int, [POINTER(SxGpModel), c_void_p, c_void_p, c_void_p]),
     'sx_gp_predict': (c_int, [POINTER(SxGpModel), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sx_onestep_reach': (c_int, [POINTER(SxEnv), c_int] + [c_void_p] * 11),

@@ -2,7 +2,8 @@
 //
 // For output d the predictive variance is  s_d + noise_d - || W_d k*_d ||^2  with  W_d = chol(K_d + noise_d I)^-1
 // (lower triangular), so the dense work is the triangular product  T = W_d . Kstar_d^T  ([N x N] x [N x 16]) followed
-// by a column sum of squares.  Mean and mean-Jacobian are 1 + D more rows of the same product:
+// by a column sum of squares.  Mean and mean-Jacobian are 1 + D more rows of the same product, stored in the rows
+// N .. N + D that the padding of W_d to a multiple of 16 leaves free:
 //     R_d = [ alpha_d ; alpha_d * X_0 / l_d0^2 ; ... ]      mean = R_d[0] . k*,   J_j = R_d[1+j] . k* - z_j / l_dj^2 * mean
 //
 // v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md, "f64 MFMA does NOT use these maps"):
@@ -28,19 +29,45 @@ __host__ __device__ inline int64_t w_pairs_per_output(int nrb) { return (int64_t
 __host__ __device__ inline int64_t w_pack_doubles(int n_s, int n_pad) {
     return (int64_t)n_s * w_pairs_per_output(n_pad / 16) * 128;
 }
-__host__ __device__ inline int64_t r_pack_doubles(int n_s, int n_pad) { return (int64_t)n_s * (n_pad / 8) * 128; }
-__host__ __device__ inline int64_t a_pack_doubles(int n_s, int n_pad) {
-    return w_pack_doubles(n_s, n_pad) + r_pack_doubles(n_s, n_pad);
-}
+__host__ __device__ inline int64_t a_pack_doubles(int n_s, int n_pad) { return w_pack_doubles(n_s, n_pad); }
+// Rows N .. N + D of the padded W_d hold the mean / Jacobian rows R_d (they ride along in the last row-block(s) for
+// free), so the padding must leave room for 1 + D of them.
+__host__ __device__ inline int gp_n_pad(int n_train, int d_in) { return (n_train + 1 + d_in + 15) / 16 * 16; }
 
 // index of element (c in 0..15, k) inside a fragment-ordered strip
 __device__ __forceinline__ int frag_index(int c, int k) {
     return (((k >> 3) * 64 + ((k & 3) << 4) + c) << 1) + ((k >> 2) & 1);
 }
 
+// e^x for finite x (here x <= ln(outputscale)): round-to-nearest range reduction x = n ln2 + r, |r| <= ln2 / 2,
+// degree-13 Taylor polynomial (truncation 4e-18), ldexp.  19 VALU instructions against ~45 for the library exp,
+// and the f64 VALU is the unit this kernel's MFMAs compete with.  Error <= ~2 ulp.  -inf / NaN give NaN.
+__device__ __forceinline__ double exp_f64(double x) {
+    const double n = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;            // 1/13!
+    p = fma(p, r, 2.08767569878680989792e-09);    // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);    // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);    // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);    // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);    // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);    // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);    // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);    // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);    // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);    // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 template <int NS, int D>
 struct GpConst {
     double inv_ls2[NS * D];
+    double nh_ils2[NS * D];   // -1 / (2 l^2)
+    double log_os[NS];        // ln(outputscale)
     double outputscale[NS];
     double noise[NS];
     const double* x_train;
@@ -70,18 +97,15 @@ struct GpTileLds {
 };
 
 // MFMA work decomposition shared by host (LDS sizing) and device (stream construction).
-//   task j <  NS : the mean/Jacobian rows of output j            (n_pad / 8 fragment pairs)
-//   task j >= NS : row-block rb of W_d, rb descending             (2 (rb + 1) pairs)
+//   task j : row-block rb = nrb - 1 - j / NS of output d = j % NS (descending cost)       2 (rb + 1) fragment pairs
 // snake-assigned to the waves by cost; every task is cut into stages of 2 pairs (4 MFMAs; pair counts are even).
 __host__ __device__ inline int gp_task_of(int round, int wave, int nw) {
     return round * nw + ((round & 1) ? (nw - 1 - wave) : wave);
 }
-__host__ __device__ inline int gp_task_pairs(int j, int ns, int nrb) {
-    return j < ns ? 2 * nrb : 2 * (nrb - (j - ns) / ns);
-}
+__host__ __device__ inline int gp_task_pairs(int j, int ns, int nrb) { return 2 * (nrb - j / ns); }
 constexpr int kStagePad = 8;  // dummy descriptors behind a wave's stream: prefetches past the end stay in bounds
 inline int gp_stage_cap(int ns, int n_pad, int nw) {
-    const int nrb = n_pad >> 4, ntask = ns * (nrb + 1), rounds = (ntask + nw - 1) / nw;
+    const int nrb = n_pad >> 4, ntask = ns * nrb, rounds = (ntask + nw - 1) / nw;
     int cap = 0;
     for (int w = 0; w < nw; ++w) {
         int n = 0;
@@ -127,10 +151,10 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
             }
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
-                double arg = 0.0;
+                double arg = gc.log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2)
 #pragma unroll
-                for (int j = 0; j < D; ++j) arg += sq[j] * gc.inv_ls2[d * D + j];
-                lds.kfrag[(size_t)d * gc.n_pad * 16 + fi] = gc.outputscale[d] * exp(-0.5 * arg);
+                for (int j = 0; j < D; ++j) arg = fma(sq[j], gc.nh_ils2[d * D + j], arg);
+                lds.kfrag[(size_t)d * gc.n_pad * 16 + fi] = exp_f64(arg);
             }
         } else {
 #pragma unroll
@@ -143,8 +167,8 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
 //
 // A wave's share of the work is static, so sx_gp_pack writes it once (build_stage_tab_kernel) to global memory as a
 // flat stream of stage descriptors
-//     int4 { x: pair offset into a_pack, y: v2d offset into kfrag, z: output d, w: flags }
-// flags: 2 = last stage of its task, 4 = mean/Jacobian rows ("extra").
+//     int4 { x: pair offset into a_pack, y: v2d offset into kfrag, z: output d | row-block << 8, w: flags }
+// flags: 2 = last stage of its task, 4 = the row-block reaches past row N (mean/Jacobian rows, zero padding).
 // One stage = 2 fragment pairs = 4 MFMAs = 256 matrix-core cycles.  Four register sets rotate, so the A fragments
 // (global: L2-resident W) and B fragments (LDS: Kstar) of stages i+1 .. i+3 are in flight while stage i computes --
 // across task boundaries too.
@@ -156,10 +180,10 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
 constexpr int kStageLast = 2, kStageExtra = 4;
 
 // one workgroup of nw waves; tab = [nw] headers, then [nw][stage_cap] descriptors
-__device__ __forceinline__ void gp_build_stage_tab(int4* tab, int ns, int n_pad, int nw, int stage_cap, int wave,
-                                                   int lane) {
+__device__ __forceinline__ void gp_build_stage_tab(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap,
+                                                   int wave, int lane) {
     const int nrb = n_pad >> 4;
-    const int ntask = ns * (nrb + 1);
+    const int ntask = ns * nrb;
     const int wpo = (int)w_pairs_per_output(nrb);
     // lane = round; (host guarantees rounds <= 64)
     const int rounds = (ntask + nw - 1) / nw;
@@ -176,21 +200,13 @@ __device__ __forceinline__ void gp_build_stage_tab(int4* tab, int ns, int n_pad,
     const int total = __shfl(incl, 63);
     int4* out = tab + nw + (size_t)wave * stage_cap;
     if (has) {
-        int d, a0, extra;
-        if (j < ns) {
-            d = j;
-            a0 = ns * wpo + j * (n_pad >> 3);  // the mean/Jacobian rows follow the W fragments in a_pack
-            extra = kStageExtra;
-        } else {
-            const int jj = j - ns;
-            const int rb = nrb - 1 - jj / ns;
-            d = jj % ns;
-            a0 = d * wpo + rb * (rb + 1);
-            extra = 0;
-        }
+        const int rb = nrb - 1 - j / ns;
+        const int d = j % ns;
+        const int a0 = d * wpo + rb * (rb + 1);
+        const int extra = (16 * rb + 15 >= n_train) ? kStageExtra : 0;  // block holds mean/Jacobian (or padding) rows
         int pos = incl - mine;
         for (int q = 0; q < npairs; q += 2, ++pos)
-            out[pos] = int4{a0 + q, d * n_pad * 8 + q * 64, d, extra | ((q + 2 >= npairs) ? kStageLast : 0)};
+            out[pos] = int4{a0 + q, d * n_pad * 8 + q * 64, d | (rb << 8), extra | ((q + 2 >= npairs) ? kStageLast : 0)};
     }
     // dummy descriptors (valid addresses, never computed on) behind the stream
     if (lane < kStagePad) out[total + lane] = int4{0, 0, 0, 0};
@@ -216,22 +232,29 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
     // which is what lets the compiler issue them as s_load
     const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * gc.stage_cap;
     const int nst = stage_tab[swave].x;
-    const char* abase = reinterpret_cast<const char*>(gc.a_pack);
-    const unsigned lane16 = (unsigned)lane * 16u;
+    // A fragments through a buffer descriptor: address = SGPR base + SGPR stage offset + constant per-lane offset,
+    // so a load needs no vector arithmetic at all
+    const __amdgpu_buffer_rsrc_t arsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gc.a_pack), 0, (int)0xffffffffu, 0x00020000);
+    const int lane16 = lane * 16;
     const v2d* kbase = reinterpret_cast<const v2d*>(lds.kfrag) + lane;
 
     // `desc` always holds the descriptor of the next stage to be issued, fetched one issue earlier.
     int4 desc = stages[0];
-    const char* ap;
+    int aoff;
     const v2d* bp;
     auto decode = [&](MfmaStage& st, int inext) {
-        ap = abase + (int64_t)desc.x * 1024;   // SGPR arithmetic
-        bp = kbase + desc.y;                   // the one VALU op of a stage
+        aoff = desc.x << 10;   // SGPR arithmetic
+        bp = kbase + desc.y;   // the one VALU op of a stage
         st.z = desc.z;
         st.w = desc.w;
         desc = stages[inext + 1];
     };
-    auto load_a = [&](int byte_off) -> v2d { return *reinterpret_cast<const v2d*>(ap + byte_off + lane16); };
+    auto load_a = [&](int byte_off) -> v2d {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(arsrc, lane16, aoff + byte_off, 0);
+        return __builtin_bit_cast(v2d, raw);
+    };
     auto issue = [&](MfmaStage& st, int i) {  // prologue form: no computing stage in front
         decode(st, i);
         st.a0 = load_a(0);
@@ -240,37 +263,47 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         st.b1 = bp[64];
     };
 
-    v4d acc0 = {0.0, 0.0, 0.0, 0.0};
-    v4d acc1 = {0.0, 0.0, 0.0, 0.0};
+    // one accumulator: a dependent chain of this MFMA issues at the full rate (tools/mfma_probe.hip)
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
     // compute stage `cur` while putting stage `inext` in flight into `nx`
     auto step = [&](const MfmaStage& cur, MfmaStage& nx, int inext) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a0.x, cur.b0.x, acc0, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a0.x, cur.b0.x, acc, 0, 0, 0);
         SX_PIN();
         decode(nx, inext);
         nx.a0 = load_a(0);
         nx.a1 = load_a(1024);
         SX_PIN();
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a0.y, cur.b0.y, acc1, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a0.y, cur.b0.y, acc, 0, 0, 0);
         SX_PIN();
         nx.b0 = bp[0];
         nx.b1 = bp[64];
         SX_PIN();
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.x, cur.b1.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.y, cur.b1.y, acc1, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.x, cur.b1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.y, cur.b1.y, acc, 0, 0, 0);
         SX_PIN();
         if (cur.w & kStageLast) {
-            const v4d t = acc0 + acc1;
+            const int d = cur.z & 255;
+            double s;
             if (cur.w & kStageExtra) {
-                // row (lane >> 4) + 4 r of the 16 extra rows, column = query point lane & 15
+                // the lane holds rows row0 + 4 r of its query point: rows < N are W rows, rows N .. N + D are the
+                // mean / Jacobian rows (to LDS), anything above is zero padding
+                const int row0 = (cur.z >> 8) * 16 + (lane >> 4);
+                s = 0.0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lds.mj[cur.z * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = t[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 4 * r;
+                    if (row < gc.n_train)
+                        s = fma(acc[r], acc[r], s);
+                    else if (row - gc.n_train <= D)
+                        lds.mj[d * 256 + (row - gc.n_train) * 16 + (lane & 15)] = acc[r];
+                }
             } else {
-                const double s = t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
-#pragma unroll
-                for (int dd = 0; dd < NS; ++dd) ssq[dd] += (cur.z == dd) ? s : 0.0;
+                s = fma(acc[3], acc[3], fma(acc[2], acc[2], fma(acc[1], acc[1], acc[0] * acc[0])));
             }
-            acc0 = v4d{0.0, 0.0, 0.0, 0.0};
-            acc1 = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int dd = 0; dd < NS; ++dd)
+                if (d == dd) ssq[dd] += s;  // d is scalar: a branch, not a select
+            acc = v4d{0.0, 0.0, 0.0, 0.0};
         }
     };
 

@@ -20,7 +20,15 @@ constexpr int kPredictThreads = 64 * SX_WAVES;
 // ---------------------------------------------------------------------------------------------------------------
 // sx_gp_pack: W_d / alpha_d -> fragment order
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void pack_w_kernel(const double* __restrict__ linv, int n_s, int n, int n_pad, double* __restrict__ w_pack) {
+template <int MAXNS, int MAXD>
+struct PackArgs {
+    double inv_ls2[MAXNS * MAXD];
+};
+
+// rows < N: W_d (lower triangular);  rows N .. N + D: alpha_d, alpha_d * X_j / l_dj^2;  above: zero
+__global__ void pack_a_kernel(const double* __restrict__ linv, const double* __restrict__ alpha,
+                              const double* __restrict__ x_train, PackArgs<SX_MAX_NS, SX_MAX_D> args, int n_s, int D, int n,
+                              int n_pad, double* __restrict__ a_pack) {
     const int nrb = n_pad >> 4;
     const int64_t wpo = w_pairs_per_output(nrb);
     const int64_t total = (int64_t)n_s * wpo * 128;
@@ -38,43 +46,19 @@ __global__ void pack_w_kernel(const double* __restrict__ linv, int n_s, int n, i
         const int row = rb * 16 + (lane & 15);
         const int k = 8 * q + 4 * slot + (lane >> 4);
         double v = 0.0;
-        if (row < n && k <= row) v = linv[((int64_t)d * n + row) * n + k];
-        w_pack[i] = v;
-    }
-}
-
-template <int MAXNS, int MAXD>
-struct PackRArgs {
-    double inv_ls2[MAXNS * MAXD];
-};
-
-__global__ void pack_r_kernel(const double* __restrict__ alpha, const double* __restrict__ x_train,
-                              PackRArgs<SX_MAX_NS, SX_MAX_D> args, int n_s, int D, int n, int n_pad,
-                              double* __restrict__ r_pack) {
-    const int ppo = n_pad >> 3;  // pairs per output
-    const int64_t total = (int64_t)n_s * ppo * 128;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int slot = (int)(i & 1);
-        const int lane = (int)((i >> 1) & 63);
-        int64_t pair = i >> 7;
-        const int d = (int)(pair / ppo);
-        const int q = (int)(pair - (int64_t)d * ppo);
-        const int row = lane & 15;
-        const int k = 8 * q + 4 * slot + (lane >> 4);
-        double v = 0.0;
-        if (k < n) {
+        if (row < n) {
+            if (k <= row) v = linv[((int64_t)d * n + row) * n + k];
+        } else if (row - n <= D && k < n) {
+            const int r = row - n;
             const double al = alpha[(int64_t)d * n + k];
-            if (row == 0)
-                v = al;
-            else if (row <= D)
-                v = al * x_train[(int64_t)k * D + row - 1] * args.inv_ls2[d * D + row - 1];
+            v = (r == 0) ? al : al * x_train[(int64_t)k * D + r - 1] * args.inv_ls2[d * D + r - 1];
         }
-        r_pack[i] = v;
+        a_pack[i] = v;
     }
 }
 
-__global__ void build_stage_tab_kernel(int4* tab, int ns, int n_pad, int nw, int stage_cap) {
-    gp_build_stage_tab(tab, ns, n_pad, nw, stage_cap, threadIdx.x >> 6, threadIdx.x & 63);
+__global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap) {
+    gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -670,7 +654,11 @@ static GpConst<NS, NS + NU> make_gp_const(const sx_gp_model* m, int nw) {
     constexpr int D = NS + NU;
     GpConst<NS, D> gc;
     for (int d = 0; d < NS; ++d) {
-        for (int j = 0; j < D; ++j) gc.inv_ls2[d * D + j] = m->inv_ls2[d * D + j];
+        for (int j = 0; j < D; ++j) {
+            gc.inv_ls2[d * D + j] = m->inv_ls2[d * D + j];
+            gc.nh_ils2[d * D + j] = -0.5 * m->inv_ls2[d * D + j];
+        }
+        gc.log_os[d] = std::log(m->outputscale[d]);
         gc.outputscale[d] = m->outputscale[d];
         gc.noise[d] = m->noise[d];
     }
@@ -767,7 +755,7 @@ static int launch_predict(const sx_gp_model* m, const double* z, int P, double* 
                           hipStream_t stream) {
     const int nw = kPredictThreads / 64;
     auto gc = make_gp_const<NS, NU>(m, nw);
-    if ((NS * ((m->n_pad >> 4) + 1) + nw - 1) / nw > 64) return SX_ERR_UNSUPPORTED;
+    if ((NS * (m->n_pad >> 4) + nw - 1) / nw > 64) return SX_ERR_UNSUPPORTED;
     const size_t lds = gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) * sizeof(double);
     if (int rc = allow_lds(gp_predict_kernel<NS, NU>, lds)) return rc;
     const int tiles = (P + SX_TILE - 1) / SX_TILE;
@@ -809,7 +797,7 @@ template <int NS, int NU>
 static int launch_rollout(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, hipStream_t stream) {
     const int nw = kRolloutThreads / 64;
     auto gc = make_gp_const<NS, NU>(m, nw);
-    if ((NS * ((m->n_pad >> 4) + 1) + nw - 1) / nw > 64) return SX_ERR_UNSUPPORTED;
+    if ((NS * (m->n_pad >> 4) + nw - 1) / nw > 64) return SX_ERR_UNSUPPORTED;
     ReachConst<NS, NU> rc;
     if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
     CostConst<SX_MAX_M, NS, NU> cc;
@@ -849,9 +837,9 @@ int sx_debug_set_stamps(unsigned long long* dev_buf) {
 
 const char* sx_version(void) { return "sxamd 0.1 gfx950"; }
 
-int sx_gp_pack_sizes(int n_s, int n_train, int64_t* a_doubles, int64_t* tab_ints) {
-    if (n_s <= 0 || n_s > SX_MAX_NS || n_train <= 0) return SX_ERR_ARG;
-    const int n_pad = (n_train + 15) / 16 * 16;
+int sx_gp_pack_sizes(int n_s, int n_u, int n_train, int64_t* a_doubles, int64_t* tab_ints) {
+    if (n_s <= 0 || n_s > SX_MAX_NS || n_u <= 0 || n_u > SX_MAX_NU || n_train <= 0) return SX_ERR_ARG;
+    const int n_pad = sx::gp_n_pad(n_train, n_s + n_u);
     if (a_doubles) *a_doubles = sx::a_pack_doubles(n_s, n_pad);
     if (tab_ints) *tab_ints = sx::gp_stage_tab_ints(n_s, n_pad, SX_WAVES);
     return SX_OK;
@@ -861,26 +849,21 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
     if (!model || !linv || !alpha || !model->x_train || !model->a_pack || !model->stage_tab) return SX_ERR_ARG;
     if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)
         return SX_ERR_ARG;
-    model->n_pad = (model->n_train + 15) / 16 * 16;
     const int D = model->n_s + model->n_u;
+    model->n_pad = sx::gp_n_pad(model->n_train, D);
+    if ((model->n_s * (model->n_pad >> 4) + SX_WAVES - 1) / SX_WAVES > 64) return SX_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t wt = sx::w_pack_doubles(model->n_s, model->n_pad);
-    int grid = (int)((wt + 255) / 256);
+    const int64_t total = sx::a_pack_doubles(model->n_s, model->n_pad);
+    int grid = (int)((total + 255) / 256);
     if (grid > 8192) grid = 8192;
-    if ((model->n_s * ((model->n_pad >> 4) + 1) + SX_WAVES - 1) / SX_WAVES > 64) return SX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(sx::pack_w_kernel, dim3(grid), dim3(256), 0, s, linv, model->n_s, model->n_train, model->n_pad,
-                       const_cast<double*>(model->a_pack));
-    sx::PackRArgs<SX_MAX_NS, SX_MAX_D> args;
+    sx::PackArgs<SX_MAX_NS, SX_MAX_D> args;
     std::memset(&args, 0, sizeof(args));
     for (int i = 0; i < model->n_s * D; ++i) args.inv_ls2[i] = model->inv_ls2[i];
-    const int64_t rt = sx::r_pack_doubles(model->n_s, model->n_pad);
-    grid = (int)((rt + 255) / 256);
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(sx::pack_r_kernel, dim3(grid), dim3(256), 0, s, alpha, model->x_train, args, model->n_s, D,
-                       model->n_train, model->n_pad, const_cast<double*>(model->a_pack) + wt);
+    hipLaunchKernelGGL(sx::pack_a_kernel, dim3(grid), dim3(256), 0, s, linv, alpha, model->x_train, args, model->n_s, D,
+                       model->n_train, model->n_pad, const_cast<double*>(model->a_pack));
     hipLaunchKernelGGL(sx::build_stage_tab_kernel, dim3(1), dim3(64 * SX_WAVES), 0, s,
-                       reinterpret_cast<int4*>(const_cast<int32_t*>(model->stage_tab)), model->n_s, model->n_pad,
-                       SX_WAVES, sx::gp_stage_cap(model->n_s, model->n_pad, SX_WAVES));
+                       reinterpret_cast<int4*>(const_cast<int32_t*>(model->stage_tab)), model->n_s, model->n_train,
+                       model->n_pad, SX_WAVES, sx::gp_stage_cap(model->n_s, model->n_pad, SX_WAVES));
     return sx::check_launch();
 }
 

@@ -108,7 +108,7 @@ class GpCemSSM(CemSSM):
         alpha = torch.cholesky_solve(y.t().unsqueeze(2), chol).squeeze(2).contiguous()  # [n_s x N]
 
         a_n, t_n = ctypes.c_int64(), ctypes.c_int64()
-        _lib.check(lib.sx_gp_pack_sizes(n_s, n, ctypes.byref(a_n), ctypes.byref(t_n)), 'sx_gp_pack_sizes')
+        _lib.check(lib.sx_gp_pack_sizes(n_s, n_u, n, ctypes.byref(a_n), ctypes.byref(t_n)), 'sx_gp_pack_sizes')
         a_pack = torch.empty(a_n.value, dtype=torch.float64, device=dev)
         stage_tab = torch.empty(t_n.value, dtype=torch.int32, device=dev)
         m = _lib.SxGpModel()

@@ -39,28 +39,36 @@ __device__ __forceinline__ int frag_index(int c, int k) {
     return (((k >> 3) * 64 + ((k & 3) << 4) + c) << 1) + ((k >> 2) & 1);
 }
 
-// e^x for finite x (here x <= ln(outputscale)): round-to-nearest range reduction x = n ln2 + r, |r| <= ln2 / 2,
-// degree-13 Taylor polynomial (truncation 4e-18), ldexp.  19 VALU instructions against ~45 for the library exp,
-// and the f64 VALU is the unit this kernel's MFMAs compete with.  Error <= ~2 ulp.  -inf / NaN give NaN.
-__device__ __forceinline__ double exp_f64(double x) {
-    const double n = __builtin_rint(x * 1.44269504088896338700e+00);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;            // 1/13!
-    p = fma(p, r, 2.08767569878680989792e-09);    // 1/12!
-    p = fma(p, r, 2.50521083854417187751e-08);    // 1/11!
-    p = fma(p, r, 2.75573192239858906526e-07);    // 1/10!
-    p = fma(p, r, 2.75573192239858906526e-06);    // 1/9!
-    p = fma(p, r, 2.48015873015873015873e-05);    // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);    // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);    // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);    // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);    // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);    // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
+// e^x for M finite arguments at once (here x <= ln(outputscale)): round-to-nearest range reduction x = n ln2 + r,
+// |r| <= ln2 / 2, degree-13 Taylor polynomial (truncation 4e-18), ldexp: 19 VALU instructions per value, error <= ~2 ulp
+// (-inf / NaN give NaN).  The M Horner chains advance in lock-step: a dependent f64 op issues every ~9 cycles, an
+// independent one every ~4 (tools/valu_probe.hip), and the f64 VALU is the unit this kernel's MFMAs compete with.
+template <int M>
+__device__ __forceinline__ void exp_f64_n(const double (&x)[M], double (&out)[M]) {
+    constexpr double c[12] = {1.6059043836821613e-10,  2.08767569878680989792e-09, 2.50521083854417187751e-08,
+                              2.75573192239858906526e-07, 2.75573192239858906526e-06, 2.48015873015873015873e-05,
+                              1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03,
+                              4.16666666666666666667e-02, 1.66666666666666666667e-01, 0.5};  // 1/13! .. 1/2!
+    double n[M], r[M], p[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) n[i] = __builtin_rint(x[i] * 1.44269504088896338700e+00);
+#pragma unroll
+    for (int i = 0; i < M; ++i) r[i] = fma(n[i], -6.93147180369123816490e-01, x[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) r[i] = fma(n[i], -1.90821492927058770002e-10, r[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) p[i] = c[0];
+#pragma unroll
+    for (int t = 1; t < 12; ++t) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], c[t]);
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < M; ++i) out[i] = ldexp(p[i], (int)n[i]);
 }
 
 template <int NS, int D>
@@ -140,25 +148,38 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
 #pragma unroll
     for (int j = 0; j < D; ++j) z[j] = lds.zs[c * D + j];
     const int kstep = ((int)blockDim.x - first) >> 4;
-    for (int k = ((int)threadIdx.x - first) >> 4; k < gc.n_pad; k += kstep) {
-        const int fi = frag_index(c, k);
-        if (k < gc.n_train) {
+    const size_t dstride = (size_t)gc.n_pad * 16;
+    // two training points per trip: 2 NS independent exp chains in flight per thread
+    for (int k0 = ((int)threadIdx.x - first) >> 4; k0 < gc.n_pad; k0 += 2 * kstep) {
+        double arg[2 * NS], val[2 * NS];
+        int fi[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + h * kstep;
+            fi[h] = frag_index(c, k);
+            const int kk = k < gc.n_train ? k : 0;  // clamp: the value is discarded below
             double sq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const double df = z[j] - lds.xs[k * D + j];
+                const double df = z[j] - lds.xs[kk * D + j];
                 sq[j] = df * df;
             }
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
-                double arg = gc.log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2)
+                double a = gc.log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2)
 #pragma unroll
-                for (int j = 0; j < D; ++j) arg = fma(sq[j], gc.nh_ils2[d * D + j], arg);
-                lds.kfrag[(size_t)d * gc.n_pad * 16 + fi] = exp_f64(arg);
+                for (int j = 0; j < D; ++j) a = fma(sq[j], gc.nh_ils2[d * D + j], a);
+                arg[h * NS + d] = a;
             }
-        } else {
+        }
+        exp_f64_n<2 * NS>(arg, val);
 #pragma unroll
-            for (int d = 0; d < NS; ++d) lds.kfrag[(size_t)d * gc.n_pad * 16 + fi] = 0.0;
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + h * kstep;
+            if (k < gc.n_pad) {
+#pragma unroll
+                for (int d = 0; d < NS; ++d) lds.kfrag[d * dstride + fi[h]] = (k < gc.n_train) ? val[h * NS + d] : 0.0;
+            }
         }
     }
 }

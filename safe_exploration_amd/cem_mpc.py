@@ -121,6 +121,7 @@ class FusedCemMpc:
         self._gen = torch.Generator(device=self._device)
         self._gen.manual_seed(distributed.rank_seed(seed, self._rank))
         self.last_status = 0
+        self._objective_hook = None
         # bench.py sets this to a list: (start, end) torch.cuda.Event pairs are then recorded around every
         # sx_cem_rollout launch, on the stream the kernel runs on
         self.rollout_events = None
@@ -128,6 +129,13 @@ class FusedCemMpc:
     @property
     def num_iterations(self) -> int:
         return self._num_iterations
+
+    def set_env(self, env: _lib.SxEnv, objective_hook=None) -> None:
+        """New problem constants (the pendulum's objective target moves between calls).  `objective_hook`, if given, is
+        an ``Environment.objective_cost_function`` this module has no kernel form for: it is then evaluated with torch
+        on the recorded trajectory centres, H small launches per iteration instead of none."""
+        self._env = env
+        self._objective_hook = objective_hook
 
     def sample_noise(self, episodes: int = 1) -> Tensor:
         return torch.randn((episodes, self._local_rollouts, self._horizon, self._ssm.num_actions), dtype=torch.float64,
@@ -157,7 +165,14 @@ class FusedCemMpc:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(torch.cuda.current_stream(dev))
             r = cem_rollout(self._ssm, self._env, x0, H, mean=mean, std=std, noise=eps.contiguous(),
-                            want_traj=self._record, status=status)
+                            want_traj=self._record or self._objective_hook is not None, status=status)
+            if self._objective_hook is not None:
+                n_s = self._ssm.num_states
+                centres = r['traj'][..., :n_s]                                   # [E x P x H x n_s]
+                obj = torch.zeros_like(r['obj_cost'])
+                for t in range(H):
+                    obj += self._objective_hook(centres[:, :, t].reshape(-1, n_s)).reshape(obj.shape)
+                r['obj_cost'] = obj.contiguous()
             if self.rollout_events is not None:
                 ev[1].record(torch.cuda.current_stream(dev))
                 self.rollout_events.append(ev)

@@ -120,6 +120,13 @@ class GpCemSSM(CemSSM):
         _lib.check(lib.sx_gp_pack(ctypes.byref(m), _lib.ptr(linv), _lib.ptr(alpha), _lib.stream_ptr(dev)), 'sx_gp_pack')
         self._model = m
         self._buffers = (x, a_pack, stage_tab, linv, alpha)
+        # 1/2 log det(I + K_d / noise_d) = sum log diag L_d - N/2 log noise_d
+        self._info_gain = (torch.log(torch.diagonal(chol, dim1=1, dim2=2)).sum(1) - 0.5 * n * torch.log(nz)).cpu().numpy()
+
+    def information_gain(self):
+        """[n_s] information gain of the training inputs, per output (zeros without data)."""
+        import numpy as np
+        return np.zeros(self.num_states) if self._model is None else self._info_gain.copy()
 
     @property
     def device_model(self) -> _lib.SxGpModel:

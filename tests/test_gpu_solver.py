@@ -1,0 +1,192 @@
+"""GPU: the drop-in classes end to end (CemSafeMPC.get_action, the dynamics callback, the objective hook path, GP
+hyper-parameter fit), checked against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cem as ocem
+from oracle import reachability as oreach
+from oracle.gp import ExactGP
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(x):
+    return torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=DEV)
+
+
+class Conf:
+    mpc_time_horizon = 5
+    cem_num_rollouts = 200
+    cem_num_elites = 20
+    cem_num_iterations = 4
+    cem_init_std = 0.2
+    plot_cem_optimisation = False
+    plot_cem_terminal_states = False
+    device = DEV
+    use_state_constraint = True
+    use_prior_model = True
+    exact_gp_training_iterations = 0
+    exact_gp_kernel = 'rbf'
+
+
+class Env:
+    """Environment attributes the solver reads, filled from a problems.ProblemSpec."""
+
+    def __init__(self, spec, enable_objectives, odd_hook=False):
+        self.spec, self._enable, self._odd = spec, enable_objectives, odd_hook
+        self.n_s, self.n_u = spec.n_s, spec.n_u
+        self.l_mu, self.l_sigm = spec.l_mu, spec.l_sigma
+        self.u_min_norm, self.u_max_norm = spec.u_min, spec.u_max
+        self._current_objective = -0.1
+
+    def random_action(self):
+        return np.zeros(self.n_u)
+
+    def objective_cost_function(self, ps):
+        if not self._enable:
+            return None
+        return torch.abs(torch.full_like(ps[:, 1], self._current_objective) - ps[:, 1]) * (1.0 if not self._odd else 1.0)
+
+    def get_safety_constraints(self, normalize=True):
+        return self.spec.h_mat, self.spec.h_vec, None, None
+
+
+def build_solver(enable_objectives=True, conf=Conf):
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.safempc_cem import CemSafeMPC, construct_constraints
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+    spec = problems.pendulum(n_train=120, seed=3, obj_mode=1 if enable_objectives else 0)
+    env = Env(spec, enable_objectives)
+    ssm = GpCemSSM(conf(), spec.n_s, spec.n_u)
+    ssm.set_hyperparameters(spec.lengthscale, spec.outputscale, spec.noise)
+    solver = CemSafeMPC(ssm, construct_constraints(conf(), env), env, conf(), {'lin_model': (spec.a, spec.b)},
+                        wx_feedback_cost=np.diag([1.0, 2.0]), wu_feedback_cost=25.0 * np.eye(1), beta_safety=spec.beta,
+                        safe_policy=lambda x: spec.k_fb @ x)
+    # update_model subtracts the prior, so hand it y + prior to end up with the spec's targets
+    y = spec.Y + spec.X[:, :2] @ spec.a.T + spec.X[:, 2:] @ spec.b.T
+    solver.update_model(spec.X, y, opt_hyp=False, replace_old=True)
+    gp = ExactGP(spec.X, ssm.y_train.cpu().numpy(), spec.lengthscale, spec.outputscale, spec.noise)
+    return solver, spec, gp
+
+
+@pytest.mark.parametrize('enable_objectives', [True, False])
+def test_get_action_matches_oracle(enable_objectives):
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.safempc_cem import MpcResult
+    solver, spec, gp = build_solver(enable_objectives)
+    np.testing.assert_allclose(solver._lqr.get_control_matrix(), spec.k_fb, rtol=1e-12)
+    c = Conf
+    rng = np.random.default_rng(11)
+    noise = rng.normal(size=(c.cem_num_iterations, c.cem_num_rollouts, c.mpc_time_horizon, 1))
+    x0 = np.array([0.01, -0.02])
+    mpc = solver._solver()
+    it = iter(noise)
+    mpc.sample_noise = lambda episodes=1: T(next(it)[None])
+    action, result = solver.get_action(x0)
+    ref_best, trace = ocem.cem_solve(problems.oracle_problem(spec, ocem), gp, x0, noise, c.cem_num_elites,
+                                     init_std=np.full((c.mpc_time_horizon, 1), c.cem_init_std))
+    assert ref_best is not None and result == MpcResult.FOUND_SOLUTION
+    np.testing.assert_allclose(action, ref_best[0], rtol=0, atol=1e-9)     # north_star tolerance: 1e-4
+    np.testing.assert_allclose(solver._last_mpc_actions, ref_best, rtol=0, atol=1e-9)
+    assert solver.x_train.shape == (120, 3)
+    m, v = solver.ssm_predict(spec.X[:5])
+    mo, vo, _ = gp.predict(spec.X[:5], False)
+    np.testing.assert_allclose(m, mo.T, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(v, vo.T, rtol=1e-9, atol=1e-11)
+    ig = solver.information_gain()
+    want = [np.log(np.diag(gp.L[d])).sum() - 0.5 * gp.n * np.log(gp.noise[d]) for d in range(2)]
+    np.testing.assert_allclose(ig, want, rtol=1e-9)
+
+
+def test_objective_hook_path_equals_kernel_path():
+    """An objective the module does not recognise is evaluated through the env hook on the recorded centres: same
+    numbers as the in-kernel form of the same function."""
+    solver, spec, gp = build_solver(True)
+    mpc = solver._solver()
+    rng = np.random.default_rng(2)
+    noise = T(rng.normal(size=(Conf.cem_num_iterations, 1, Conf.cem_num_rollouts, Conf.mpc_time_horizon, 1)))
+    x0 = T([[0.01, -0.02]])
+    best_a, ok_a, _, _ = mpc.solve(x0, noise=noise)
+    env, _ = solver._build_env()
+    mpc.set_env(env, objective_hook=solver._env_objective_cost_func)
+    best_b, ok_b, _, _ = mpc.solve(x0, noise=noise)
+    assert int(ok_a[0]) == int(ok_b[0]) == 1
+    np.testing.assert_allclose(best_a.cpu().numpy(), best_b.cpu().numpy(), rtol=0, atol=1e-12)
+
+
+def test_infeasible_problem_falls_back():
+    from safe_exploration_amd.safempc_cem import MpcResult
+
+    class Tight(Conf):
+        mpc_time_horizon = 12   # ellipsoids outgrow the polytope: no feasible particle
+    solver, spec, gp = build_solver(False, Tight)
+    action, result = solver.get_action(np.array([0.3, 0.3]))
+    assert result == MpcResult.SAFE_CONTROLLER
+    np.testing.assert_allclose(action, spec.k_fb @ np.array([0.3, 0.3]))
+
+
+def test_dynamics_callback_matches_oracle():
+    """CemSafeMPC._dynamics_func (the reference's DynamicsFunc contract, safempc_cem.py:288-302) on flat states."""
+    solver, spec, gp = build_solver(False)
+    rng = np.random.default_rng(4)
+    P = 33
+    p = rng.normal(0, 0.05, size=(P, 2))
+    m = rng.normal(size=(P, 2, 2))
+    q = 0.01 * (m @ m.transpose(0, 2, 1) + 0.5 * np.eye(2))
+    u = rng.uniform(-0.3, 0.3, size=(P, 1))
+    flat = T(np.concatenate((p, q.reshape(P, -1)), axis=1))
+    nxt, cost = solver._dynamics_func(flat, T(u))
+    p1, q1, sig, _ = oreach.onestep_reachability(p, gp, u, spec.l_mu, spec.l_sigma, q, spec.k_fb, spec.beta, a=spec.a,
+                                                 b=spec.b)
+    np.testing.assert_allclose(nxt.cpu().numpy(), oreach.pq_flatten(p1, q1), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cost.cpu().numpy(), -sig.sum(1), rtol=1e-9, atol=1e-12)
+    # point start: all-zero Q block means "None"
+    nxt0, _ = solver._dynamics_func(T(np.concatenate((p, np.zeros((P, 4))), axis=1)), T(u))
+    p1, q1, _, _ = oreach.onestep_reachability(p, gp, u, spec.l_mu, spec.l_sigma, None, spec.k_fb, spec.beta, a=spec.a,
+                                               b=spec.b)
+    np.testing.assert_allclose(nxt0.cpu().numpy(), oreach.pq_flatten(p1, q1), rtol=1e-9, atol=1e-12)
+
+
+def test_gp_without_data_predicts_the_prior_and_training_lowers_the_loss():
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+
+    class TrainConf(Conf):
+        exact_gp_training_iterations = 30
+    ssm = GpCemSSM(TrainConf(), 2, 1)
+    m, v, j = ssm.predict_with_jacobians(T(np.zeros((3, 2))), T(np.zeros((3, 1))))
+    assert m.shape == (3, 2) and j.shape == (3, 2, 3) and float(m.abs().max()) == 0.0
+    np.testing.assert_allclose(v.cpu().numpy(), np.log(2) * 2 + 1e-4)        # softplus(0) + softplus(0) + floor
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, size=(60, 3))
+    Y = np.stack([np.sin(2 * X[:, 0]) + 0.01 * rng.normal(size=60), X[:, 1] * X[:, 2]], 1)
+    ssm.update_model(T(X), T(Y), opt_hyp=True, replace_old=True)
+    losses = ssm.collect_metrics()['losses']
+    assert len(losses) == 30 and losses[-1] < losses[0]
+    gp = ExactGP(X, Y, ssm.lengthscale.numpy(), ssm.outputscale.numpy(), ssm.noise.numpy())
+    z = rng.uniform(-1, 1, size=(10, 3))
+    mo, vo, jo = gp.predict(z)
+    m, v, j = ssm.predict_with_jacobians(T(z[:, :2]), T(z[:, 2:]))
+    np.testing.assert_allclose(m.cpu().numpy(), mo, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(v.cpu().numpy(), vo, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(j.cpu().numpy(), jo, rtol=1e-8, atol=1e-10)
+    with pytest.raises(ValueError):
+        ssm.predict_raw(T(np.zeros((3, 2))))                                   # wrong input width
+
+
+def test_nan_status_raises_value_error():
+    """A NaN at the reference's zero/NaN checks aborts the solve with ValueError (gp_reachability_pytorch.py:76-80)."""
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.cem_mpc import FusedCemMpc
+    spec = problems.pendulum(n_train=64)
+    ssm, env = problems.build(spec, DEV)
+    mpc = FusedCemMpc(ssm, env, 4, 64, 8, 2, device=DEV)
+    flat = torch.zeros((1, 6), dtype=torch.float64, device=DEV)
+    flat[0, 0] = float('nan')
+    with pytest.raises(ValueError):
+        mpc.get_actions(flat)
+    with pytest.raises(NotImplementedError):
+        mpc.get_actions(torch.ones((1, 6), dtype=torch.float64, device=DEV))   # non-point start
+    with pytest.raises(ValueError):
+        mpc.get_actions(torch.zeros((1, 5), dtype=torch.float64, device=DEV))

@@ -1,0 +1,260 @@
+"""CPU: host-side logic of the boundary classes, mirroring the reference's own tests where they exist
+(safe_exploration/test/test_safempc_cem.py, test_ssm_cem.py).  pytest-mock is not installed: unittest.mock stands in."""
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch
+
+from safe_exploration_amd import _lib, distributed
+from safe_exploration_amd.gp_reachability_pytorch import make_env, raise_for_status
+from safe_exploration_amd.safempc_cem import (ActionConstraint, CemSafeMPC, EllipsoidStateConstraint,
+                                              EllipsoidTerminalConstraint, LqrFeedbackController, MpcResult, PQFlattener,
+                                              construct_constraints, objective_spec)
+from safe_exploration_amd.ssm_cem.ssm_cem import CemSSM
+from safe_exploration_amd.utils import assert_shape, dlqr, get_device
+
+
+class FakeConfig:   # test_safempc_cem.py:11-20
+    mpc_time_horizon = 2
+    cem_num_rollouts = 20
+    cem_num_elites = 3
+    cem_num_iterations = 8
+    plot_cem_optimisation = False
+    plot_cem_terminal_states = False
+    device = 'cpu'
+    use_state_constraint = False
+    use_prior_model = True
+
+
+class FakePendulum:
+    """The attributes CemSafeMPC / construct_constraints read from an Environment."""
+    n_s, n_u = 2, 1
+    l_mu = np.array([0.05, 0.02])
+    l_sigm = np.array([0.05, 0.02])
+    u_min_norm = np.array([-1.0])
+    u_max_norm = np.array([1.0])
+    _current_objective = -0.1
+
+    def __init__(self, enable_objectives=False):
+        self._enable = enable_objectives
+
+    def random_action(self):
+        return np.zeros(1)
+
+    def objective_cost_function(self, ps):
+        if not self._enable:
+            return None
+        return torch.abs(torch.full_like(ps[:, 1], self._current_objective) - ps[:, 1])
+
+    def get_safety_constraints(self, normalize=True):
+        return np.array([[1., 0.], [-1., 0.], [0., 1.], [0., -1.]]), np.array([[.8], [.8], [.35], [.35]]), None, None
+
+
+class FakeLander(FakePendulum):
+    n_s = 6
+
+    def objective_cost_function(self, ps):
+        return -ps[:, -1]
+
+
+class TestPQFlattener:   # test_safempc_cem.py:23-42
+    def test_roundtrip_with_q(self):
+        f = PQFlattener(state_dimen=3)
+        p = torch.tensor([[1, 2, 3], [10, 20, 30]])
+        q = torch.tensor([[[10, 11, 12], [20, 21, 22], [30, 31, 32]], [[20, 21, 22], [30, 31, 32], [50, 51, 52]]])
+        flat = f.flatten(p, q)
+        assert flat[0].tolist() == [1, 2, 3, 10, 11, 12, 20, 21, 22, 30, 31, 32]   # [p | vec_rowmajor(Q)]
+        p_out, q_out = f.unflatten(flat)
+        assert torch.equal(p, p_out) and torch.equal(q, q_out)
+
+    def test_roundtrip_q_none(self):
+        f = PQFlattener(state_dimen=4)
+        p = torch.tensor([[1, 2, 3, 4], [10, 20, 30, 40]])
+        p_out, q_out = f.unflatten(f.flatten(p, None))
+        assert torch.equal(p, p_out) and q_out is None
+
+    def test_flat_dimen(self):
+        assert PQFlattener(state_dimen=5).get_flat_state_dimen() == 5 + 5 * 5
+
+    def test_bad_shape_raises_value_error(self):
+        with pytest.raises(ValueError):
+            PQFlattener(3).flatten(torch.zeros(2, 4), None)
+
+
+def test_construct_constraints():   # test_safempc_cem.py:45-71
+    cs = construct_constraints(FakeConfig(), FakePendulum())
+    assert len([c for c in cs if isinstance(c, EllipsoidTerminalConstraint)]) == 1
+    assert len([c for c in cs if isinstance(c, ActionConstraint)]) == 1
+
+    class StateConf(FakeConfig):
+        use_state_constraint = True
+    cs = construct_constraints(StateConf(), FakePendulum())
+    assert len([c for c in cs if isinstance(c, EllipsoidStateConstraint)]) == 1
+
+
+def test_action_constraint_known_answer():   # test_safempc_cem.py:59-71
+    c = ActionConstraint(np.array([-4.0]), np.array([4.0]))
+    trajectory = torch.zeros((3, 4), dtype=torch.double)
+    actions = torch.tensor([[0.2], [-5.], [6.]], dtype=torch.double)
+    assert c(trajectory, actions) == 2 * 3
+
+
+def _safe_policy(x):
+    return np.dot(x, np.eye(2))
+
+
+def _solver(mpc, lqr=None):
+    ssm = mock.Mock()
+    ssm.x_train = None
+    s = CemSafeMPC(ssm, [], FakePendulum(), FakeConfig(), {'lin_model': ([0.1, 0.2])}, wx_feedback_cost=None,
+                   wu_feedback_cost=None, lqr=lqr or mock.Mock(), mpc=mpc, beta_safety=1.0, safe_policy=_safe_policy)
+    s.update_model(np.array([[0.1, 0.2, 0.3]]), np.array([[0.1, 0.1]]))
+    return s, ssm
+
+
+class TestFallbackLadder:   # test_safempc_cem.py:74-148
+    def test_solution_found(self):
+        mpc = mock.Mock()
+        mpc.get_actions.return_value = (torch.tensor([[0.1], [0.2]]), [])
+        s, ssm = _solver(mpc)
+        action, result = s.get_action(np.array([0., 0.]))
+        assert np.allclose(action, [0.1]) and result == MpcResult.FOUND_SOLUTION
+        flat = mpc.get_actions.call_args[0][0]
+        assert tuple(flat.shape) == (1, 6) and bool((flat[:, 2:] == 0).all())   # point start: all-zero Q block
+        x, y, opt_hyp, replace_old = ssm.update_model.call_args[0]
+        # the model learns the error to the prior: y - (x_s a^T + x_u b^T)
+        np.testing.assert_allclose(y.numpy(), [[0.1 - (0.1 * 0.1 + 0.3 * 0.2), 0.1 - (0.2 * 0.1 + 0.3 * 0.2)]])
+
+    def test_previous_solution(self):
+        mpc = mock.Mock()
+        mpc.get_actions.side_effect = [(torch.tensor([[0.1], [0.2]]), []), (None, [])]
+        s, _ = _solver(mpc)
+        s.get_action(np.array([0., 0.]))
+        action, result = s.get_action(np.array([0., 0.]))
+        assert np.allclose(action, [0.2]) and result == MpcResult.PREVIOUS_SOLUTION
+
+    def test_safe_controller_when_nothing_to_fall_back_on(self):
+        mpc = mock.Mock()
+        mpc.get_actions.side_effect = [(None, [])]
+        s, _ = _solver(mpc)
+        action, result = s.get_action(np.array([1., 2.]))
+        assert np.allclose(action, [1., 2.]) and result == MpcResult.SAFE_CONTROLLER
+
+    def test_safe_controller_when_previous_solution_runs_out(self):
+        mpc = mock.Mock()
+        mpc.get_actions.side_effect = [(torch.tensor([[0.1], [0.2]]), []), (None, []), (None, [])]
+        s, _ = _solver(mpc)
+        s.get_action(np.array([0., 0.]))
+        s.get_action(np.array([0., 0.]))
+        action, result = s.get_action(np.array([1., 2.]))
+        assert np.allclose(action, [1., 2.]) and result == MpcResult.SAFE_CONTROLLER
+
+    def test_bad_state_shape(self):
+        s, _ = _solver(mock.Mock())
+        with pytest.raises(ValueError):
+            s.get_action(np.zeros(3))
+
+    def test_read_only_members(self):
+        s, ssm = _solver(mock.Mock())
+        assert (s.state_dimen, s.action_dimen, s.safety_trajectory_length, s.performance_trajectory_length) == (2, 1, 2, 0)
+        assert s.x_train.shape == (0, 3) and s.ssm is ssm and s.lin_model == [0.1, 0.2]
+        with pytest.raises(NotImplementedError):
+            s.get_action_verbose(np.zeros(2))
+
+
+def test_objective_spec_mapping():
+    mode, w_abs, tgt, w_lin = objective_spec(FakePendulum(False))
+    assert mode == _lib.SX_OBJ_NEG_VARIANCE
+    mode, w_abs, tgt, w_lin = objective_spec(FakePendulum(True))
+    assert mode == _lib.SX_OBJ_AFFINE_ABS and w_abs.tolist() == [0, 1] and tgt.tolist() == [0, -0.1]
+    mode, w_abs, tgt, w_lin = objective_spec(FakeLander())
+    assert mode == _lib.SX_OBJ_AFFINE_ABS and w_lin.tolist() == [0, 0, 0, 0, 0, -1] and not w_abs.any()
+
+    class Odd(FakePendulum):
+        n_s = 3
+
+        def objective_cost_function(self, ps):
+            return (ps ** 2).sum(1)
+    assert objective_spec(Odd()) is None     # unknown hook -> evaluated through the hook itself
+
+
+def test_cem_ssm_update_model_bookkeeping():   # test_ssm_cem.py: data management of the ABC
+    class Dummy(CemSSM):
+        updates = 0
+        trained = 0
+
+        def _update_model(self, x, y):
+            self.updates += 1
+
+        def _train_model(self, x, y):
+            self.trained += 1
+
+        def predict_with_jacobians(self, s, a): ...
+        def predict_without_jacobians(self, s, a): ...
+        def predict_raw(self, z): ...
+        def collect_metrics(self): return {}
+        parametric = False
+
+    m = Dummy(2, 1)
+    assert m.x_train is None and m.y_train is None
+    m.update_model(torch.zeros(3, 3), torch.zeros(3, 2))
+    m.update_model(torch.ones(2, 3), torch.ones(2, 2))                       # merged
+    assert m.x_train.shape == (5, 3) and m.y_train.shape == (5, 2) and m.trained == 0
+    m.update_model(torch.ones(4, 3), torch.ones(4, 2), opt_hyp=True, replace_old=True)
+    assert m.x_train.shape == (4, 3) and m.updates == 3 and m.trained == 1
+    with pytest.raises(ValueError):
+        m.update_model(torch.zeros(3, 2), torch.zeros(3, 2))
+    with pytest.raises(ValueError):
+        m._join_states_actions(torch.zeros(3, 2), torch.zeros(4, 1))
+
+
+def test_utils():
+    assert_shape(np.zeros((2, 3)), (2, 3))
+    assert_shape(None, (1,), ignore_if_none=True)
+    with pytest.raises(ValueError):
+        assert_shape(None, (1,))
+    with pytest.raises(ValueError):
+        assert_shape(np.zeros(3), (4,))
+    assert get_device('cpu') == 'cpu' and get_device(FakeConfig()) == 'cpu'
+    a = np.array([[1.0, 0.1], [0.0, 1.0]])
+    b = np.array([[0.0], [0.1]])
+    k, x, ev = dlqr(a, b, np.eye(2), np.eye(1))
+    assert (np.abs(ev) < 1).all()
+    np.testing.assert_allclose(x, a.T @ x @ a - a.T @ x @ b @ k + np.eye(2), atol=1e-9)   # the DARE residual
+    ctl = LqrFeedbackController(np.eye(2), np.eye(1), 2, 1, a, b, conf='cpu')
+    np.testing.assert_allclose(ctl.get_control_matrix(), -k)
+    assert tuple(ctl.get_control_matrix_pytorch().shape) == (1, 2)
+
+
+def test_make_env_and_status_mapping():
+    env = make_env(2, 1, k_fb=[[1, 2]], l_mu=[.1, .2], l_sigma=[.3, .4], beta=2.0, h_mat=np.eye(2), h_vec=[[1], [2]],
+                   u_min=[-1], u_max=[1])
+    assert (env.n_s, env.n_u, env.m, env.beta) == (2, 1, 2, 2.0)
+    assert list(env.a)[:4] == [1, 0, 0, 1] and list(env.k_fb)[:2] == [1, 2] and list(env.h_vec)[:2] == [1, 2]
+    with pytest.raises(ValueError):
+        make_env(2, 1, h_mat=np.zeros((17, 2)), h_vec=np.zeros(17))
+    with pytest.raises(ValueError):
+        make_env(7, 1)
+    raise_for_status(0, 'x')
+    with pytest.raises(ValueError):
+        raise_for_status(_lib.SX_STATUS_NAN, 'x')
+    with pytest.raises(AssertionError):
+        raise_for_status(_lib.SX_STATUS_UB_NONPOS, 'x')
+    raise_for_status(_lib.SX_STATUS_ZERO_FIX, 'x')    # warning only
+
+
+def test_cpu_tensors_are_refused():
+    from safe_exploration_amd.gp_reachability_pytorch import lin_ellipsoid_safety_distance
+    with pytest.raises(_lib.SxError, match='no CPU path'):
+        lin_ellipsoid_safety_distance(torch.zeros(1, 2, dtype=torch.float64), torch.zeros(1, 2, 2, dtype=torch.float64),
+                                      torch.eye(2, dtype=torch.float64), torch.ones(2, 1, dtype=torch.float64))
+
+
+def test_shard_particles_and_seeds():
+    for total, world in ((4096, 1), (65536, 8), (10, 4), (7, 8)):
+        counts = [distributed.shard_particles(total, world, r) for r in range(world)]
+        assert sum(c for c, _ in counts) == total
+        assert [o for _, o in counts] == list(np.cumsum([0] + [c for c, _ in counts])[:-1])
+    assert distributed.rank_seed(1, 0) != distributed.rank_seed(1, 1)
+    assert distributed.world_and_rank(None) == (1, 0)

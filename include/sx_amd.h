@@ -96,6 +96,17 @@ const char* sx_version(void);
 /* Sizes of sx_gp_model.a_pack (doubles) and sx_gp_model.stage_tab (int32). */
 int sx_gp_pack_sizes(int n_s, int n_u, int n_train, int64_t* a_doubles, int64_t* tab_ints);
 
+#define SX_STATUS_NOT_PD 8       /* sx_gp_fit: K + noise I is not positive definite (gpytorch would raise too) */
+
+/* Exact-GP fit for fixed hyper-parameters: K_d + noise_d I = L_d L_d^T, linv = L_d^-1 (dev [n_s x N x N]),
+ * alpha_d = (K_d + noise_d I)^-1 y_d (dev [n_s x N]), logdet_d = sum log diag L_d (dev [n_s]).
+ * model->{n_s,n_u,n_train,inv_ls2,outputscale,noise,x_train} must be set; y_train dev [N x n_s];
+ * work dev [n_s x N x N] scratch (holds L on return); status dev int32 (SX_STATUS_NOT_PD).  N <= 4096.
+ * Replaces: what gpytorch's ExactGP computes when GpCemSSM sets new training data
+ * (ssm_cem/gp_ssm_cem.py:96-101, ssm_pytorch/gaussian_process.py:82-140). */
+int sx_gp_fit(const sx_gp_model* model, const double* y_train, double* work, double* linv, double* alpha,
+              double* logdet, int32_t* status, void* stream);
+
 /* Lays W_d = L_d^-1 (dev [n_s x N x N], lower triangular) and alpha (dev [n_s x N]) out in fragment order.
  * model->{n_s,n_u,n_train,inv_ls2,x_train,a_pack,stage_tab} must be set; n_pad is filled in.
  * Replaces: GpCemSSM._update_model (ssm_cem/gp_ssm_cem.py:96-101) -- where the prediction operands are (re)built. */

@@ -13,7 +13,7 @@ SX_MAX_M = 16
 SX_TILE = 16
 
 SX_OK, SX_ERR_ARG, SX_ERR_UNSUPPORTED, SX_ERR_LAUNCH = 0, 1, 2, 3
-SX_STATUS_NAN, SX_STATUS_ZERO_FIX, SX_STATUS_UB_NONPOS = 1, 2, 4
+SX_STATUS_NAN, SX_STATUS_ZERO_FIX, SX_STATUS_UB_NONPOS, SX_STATUS_NOT_PD = 1, 2, 4, 8
 SX_OBJ_NEG_VARIANCE, SX_OBJ_AFFINE_ABS = 0, 1
 SX_CON_TERMINAL, SX_CON_ALL_STATES = 0, 1
 
@@ -44,6 +44,7 @@ class SxEnv(Structure):
 SIGNATURES = {
     'sx_version': (c_char_p, []),
     'sx_gp_pack_sizes': (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    'sx_gp_fit': (c_int, [POINTER(SxGpModel)] + [c_void_p] * 7),
     'sx_gp_pack': (c_int, [POINTER(SxGpModel), c_void_p, c_void_p, c_void_p]),
     'sx_gp_predict': (c_int, [POINTER(SxGpModel), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sx_onestep_reach': (c_int, [POINTER(SxEnv), c_int] + [c_void_p] * 11),

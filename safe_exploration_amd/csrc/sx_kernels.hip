@@ -57,6 +57,109 @@ __global__ void pack_a_kernel(const double* __restrict__ linv, const double* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_fit: K_d + noise_d I = L_d L_d^T, W_d = L_d^-1, alpha_d = W_d^T W_d y_d, log det L_d.   Warm path: once per
+// update_model.  One 1024-thread workgroup per output, everything in place in global memory (a workgroup lives on one
+// CU, so its own stores are visible to it after a barrier); the active column / row is staged in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFitThreads = 1024;
+constexpr int kFitMaxN = 4096;
+
+struct FitArgs {
+    double inv_ls2[SX_MAX_NS * SX_MAX_D];
+    double outputscale[SX_MAX_NS];
+    double noise[SX_MAX_NS];
+    const double* x;   // [N x D]
+    const double* y;   // [N x n_s]
+    double* lmat;      // [n_s x N x N]  K then L (lower triangle)
+    double* linv;      // [n_s x N x N]  W = L^-1
+    double* alpha;     // [n_s x N]
+    double* logdet;    // [n_s]  sum log diag L
+    int* status;
+    int n, D, n_s;
+};
+
+__global__ __launch_bounds__(kFitThreads) void gp_fit_kernel(FitArgs fa) {
+    __shared__ double vec[kFitMaxN];
+    __shared__ double red[kFitThreads];
+    const int d = blockIdx.x, tid = threadIdx.x, n = fa.n, D = fa.D;
+    double* A = fa.lmat + (size_t)d * n * n;
+    double* W = fa.linv + (size_t)d * n * n;
+    // 1. kernel matrix (lower triangle)
+    for (int64_t idx = tid; idx < (int64_t)n * n; idx += kFitThreads) {
+        const int i = (int)(idx / n), j = (int)(idx - (int64_t)i * n);
+        if (j <= i) {
+            double q = 0.0;
+            for (int c = 0; c < D; ++c) {
+                const double df = fa.x[(size_t)i * D + c] - fa.x[(size_t)j * D + c];
+                q += df * df * fa.inv_ls2[d * D + c];
+            }
+            A[idx] = fa.outputscale[d] * exp(-0.5 * q) + (i == j ? fa.noise[d] : 0.0);
+        }
+    }
+    __syncthreads();
+    // 2. right-looking Cholesky
+    const int ty = tid >> 6, tx = tid & 63;
+    bool bad = false;
+    for (int j = 0; j < n; ++j) {
+        const double ajj = A[(size_t)j * n + j];
+        const double piv = sqrt(ajj);
+        if (!(ajj > 0.0)) bad = true;
+        for (int i = j + 1 + tid; i < n; i += kFitThreads) {
+            const double v = A[(size_t)i * n + j] / piv;
+            A[(size_t)i * n + j] = v;
+            vec[i] = v;
+        }
+        __syncthreads();
+        if (tid == 0) A[(size_t)j * n + j] = piv;
+        for (int i = j + 1 + ty; i < n; i += kFitThreads / 64) {
+            const double li = vec[i];
+            double* row = A + (size_t)i * n;
+            for (int c = j + 1 + tx; c <= i; c += 64) row[c] -= li * vec[c];
+        }
+        __syncthreads();
+    }
+    if (bad && tid == 0) atomicOr(fa.status, 8);
+    // 3. W = L^-1, row by row: W[i][c] = (delta_ic - sum_{k=c}^{i-1} L[i][k] W[k][c]) / L[i][i]
+    for (int i = 0; i < n; ++i) {
+        for (int c = tid; c <= i; c += kFitThreads) vec[c] = A[(size_t)i * n + c];
+        __syncthreads();
+        const double inv = 1.0 / vec[i];
+        for (int c = tid; c < n; c += kFitThreads) {
+            double w = 0.0;
+            if (c <= i) {
+                double s = (c == i) ? 1.0 : 0.0;
+                for (int kk = c; kk < i; ++kk) s -= vec[kk] * W[(size_t)kk * n + c];
+                w = s * inv;
+            }
+            W[(size_t)i * n + c] = w;
+        }
+        __syncthreads();
+    }
+    // 4. alpha = W^T (W y)
+    for (int i = tid; i < n; i += kFitThreads) {
+        double s = 0.0;
+        for (int c = 0; c <= i; ++c) s += W[(size_t)i * n + c] * fa.y[(size_t)c * fa.n_s + d];
+        vec[i] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += kFitThreads) {
+        double s = 0.0;
+        for (int i = c; i < n; ++i) s += W[(size_t)i * n + c] * vec[i];
+        fa.alpha[(size_t)d * n + c] = s;
+    }
+    // 5. sum log diag L
+    double ld = 0.0;
+    for (int i = tid; i < n; i += kFitThreads) ld += log(A[(size_t)i * n + i]);
+    red[tid] = ld;
+    __syncthreads();
+    for (int off = kFitThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) fa.logdet[d] = red[0];
+}
+
 __global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap) {
     gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x >> 6, threadIdx.x & 63);
 }
@@ -843,6 +946,34 @@ int sx_gp_pack_sizes(int n_s, int n_u, int n_train, int64_t* a_doubles, int64_t*
     if (a_doubles) *a_doubles = sx::a_pack_doubles(n_s, n_pad);
     if (tab_ints) *tab_ints = sx::gp_stage_tab_ints(n_s, n_pad, SX_WAVES);
     return SX_OK;
+}
+
+int sx_gp_fit(const sx_gp_model* model, const double* y_train, double* work, double* linv, double* alpha,
+              double* logdet, int32_t* status, void* stream) {
+    if (!model || !model->x_train || !y_train || !work || !linv || !alpha || !logdet || !status) return SX_ERR_ARG;
+    if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)
+        return SX_ERR_ARG;
+    if (model->n_train > sx::kFitMaxN) return SX_ERR_UNSUPPORTED;
+    sx::FitArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    const int D = model->n_s + model->n_u;
+    for (int i = 0; i < model->n_s * D; ++i) fa.inv_ls2[i] = model->inv_ls2[i];
+    for (int i = 0; i < model->n_s; ++i) {
+        fa.outputscale[i] = model->outputscale[i];
+        fa.noise[i] = model->noise[i];
+    }
+    fa.x = model->x_train;
+    fa.y = y_train;
+    fa.lmat = work;
+    fa.linv = linv;
+    fa.alpha = alpha;
+    fa.logdet = logdet;
+    fa.status = status;
+    fa.n = model->n_train;
+    fa.D = D;
+    fa.n_s = model->n_s;
+    hipLaunchKernelGGL(sx::gp_fit_kernel, dim3(model->n_s), dim3(sx::kFitThreads), 0, (hipStream_t)stream, fa);
+    return sx::check_launch();
 }
 
 int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void* stream) {

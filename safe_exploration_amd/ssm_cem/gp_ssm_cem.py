@@ -99,14 +99,7 @@ class GpCemSSM(CemSSM):
         dev = x_train.device
         n_s, n_u, n = self.num_states, self.num_actions, x_train.size(0)
         x = x_train.detach().contiguous()
-        y = y_train.detach()
-        ls, s, nz = self.lengthscale.to(dev), self.outputscale.to(dev), self.noise.to(dev)
-        k = self._kernel_matrices(x, ls, s, nz)
-        chol = torch.linalg.cholesky(k)                                     # [n_s x N x N] lower
-        eye = torch.eye(n, dtype=torch.float64, device=dev).expand(n_s, n, n)
-        linv = torch.linalg.solve_triangular(chol, eye, upper=False).contiguous()
-        alpha = torch.cholesky_solve(y.t().unsqueeze(2), chol).squeeze(2).contiguous()  # [n_s x N]
-
+        y = y_train.detach().contiguous()
         a_n, t_n = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(lib.sx_gp_pack_sizes(n_s, n_u, n, ctypes.byref(a_n), ctypes.byref(t_n)), 'sx_gp_pack_sizes')
         a_pack = torch.empty(a_n.value, dtype=torch.float64, device=dev)
@@ -117,11 +110,23 @@ class GpCemSSM(CemSSM):
         _lib.fill(m.outputscale, self.outputscale.numpy())
         _lib.fill(m.noise, self.noise.numpy())
         m.x_train, m.a_pack, m.stage_tab = x.data_ptr(), a_pack.data_ptr(), stage_tab.data_ptr()
-        _lib.check(lib.sx_gp_pack(ctypes.byref(m), _lib.ptr(linv), _lib.ptr(alpha), _lib.stream_ptr(dev)), 'sx_gp_pack')
+        # factorise on the device (sx_gp_fit), then lay the operands out for the matrix cores (sx_gp_pack)
+        work = torch.empty((n_s, n, n), dtype=torch.float64, device=dev)
+        linv = torch.empty((n_s, n, n), dtype=torch.float64, device=dev)
+        alpha = torch.empty((n_s, n), dtype=torch.float64, device=dev)
+        logdet = torch.empty((n_s,), dtype=torch.float64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        stream = _lib.stream_ptr(dev)
+        _lib.check(lib.sx_gp_fit(ctypes.byref(m), _lib.ptr(y), _lib.ptr(work), _lib.ptr(linv), _lib.ptr(alpha),
+                                 _lib.ptr(logdet), _lib.ptr(status), stream), 'sx_gp_fit')
+        _lib.check(lib.sx_gp_pack(ctypes.byref(m), _lib.ptr(linv), _lib.ptr(alpha), stream), 'sx_gp_pack')
+        if int(status.item()) & _lib.SX_STATUS_NOT_PD:
+            raise RuntimeError('the kernel matrix K + noise I is not positive definite for the current hyper-parameters')
         self._model = m
-        self._buffers = (x, a_pack, stage_tab, linv, alpha)
+        self._buffers = (x, a_pack, stage_tab)
+        self._alpha = alpha
         # 1/2 log det(I + K_d / noise_d) = sum log diag L_d - N/2 log noise_d
-        self._info_gain = (torch.log(torch.diagonal(chol, dim1=1, dim2=2)).sum(1) - 0.5 * n * torch.log(nz)).cpu().numpy()
+        self._info_gain = (logdet.cpu() - 0.5 * n * torch.log(self.noise)).numpy()
 
     def information_gain(self):
         """[n_s] information gain of the training inputs, per output (zeros without data)."""

@@ -190,3 +190,58 @@ def test_nan_status_raises_value_error():
         mpc.get_actions(torch.ones((1, 6), dtype=torch.float64, device=DEV))   # non-point start
     with pytest.raises(ValueError):
         mpc.get_actions(torch.zeros((1, 5), dtype=torch.float64, device=DEV))
+
+
+def test_batched_episodes_match_single_solves():
+    """Config-5 shape in small: E independent problems in one launch == E separate solves == the oracle."""
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.cem_mpc import FusedCemMpc
+    spec = problems.pendulum(n_train=100, seed=1, obj_mode=1)
+    ssm, env = problems.build(spec, DEV)
+    gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+    E, P, H, k, iters = 5, 96, 5, 10, 3
+    rng = np.random.default_rng(21)
+    noise = rng.normal(size=(iters, E, P, H, 1))
+    x0 = rng.normal(0, 0.03, size=(E, 2))
+    mpc = FusedCemMpc(ssm, env, H, P, k, iters, device=DEV, init_std=0.2)
+    best, ok, _, status = mpc.solve(T(x0), noise=T(noise))
+    assert int(status.item()) == 0
+    for e in range(E):
+        ref, _ = ocem.cem_solve(problems.oracle_problem(spec, ocem), gp, x0[e], noise[:, e], k,
+                                init_std=np.full((H, 1), 0.2))
+        assert (ref is not None) == bool(ok[e])
+        if ref is not None:
+            np.testing.assert_allclose(best[e].cpu().numpy(), ref, rtol=0, atol=1e-9)
+        one, ok1, _, _ = mpc.solve(T(x0[e:e + 1]), noise=T(noise[:, e:e + 1]))
+        assert torch.equal(one[0], best[e]) and int(ok1[0]) == int(ok[e])
+
+
+def test_cartpole_sized_rollout_vs_oracle():
+    """n_s = 4 (Jacobi eigen-solve, 9-row polytope) through the fused rollout."""
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.cem_mpc import cem_rollout
+    spec = problems.cartpole(n_train=150, seed=2)
+    ssm, env = problems.build(spec, DEV)
+    gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+    P, H = 70, 6
+    rng = np.random.default_rng(8)
+    acts = rng.normal(0, 0.6, size=(P, H, 1))
+    x0 = np.array([0.05, -0.02, 0.01, 0.03])
+    r = cem_rollout(ssm, env, T(x0[None]), H, actions=T(acts[None]), want_traj=True, want_sigma=True)
+    ref = ocem.rollout(problems.oracle_problem(spec, ocem), gp, x0, acts)
+    traj = r['traj'][0].cpu().numpy()
+    np.testing.assert_allclose(traj[:, :, :4], ref.traj_p, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(traj[:, :, 4:].reshape(P, H, 4, 4), ref.traj_q, rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(r['sigma'][0].cpu().numpy(), ref.sigma, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(r['obj_cost'][0].cpu().numpy(), ref.obj_cost, rtol=1e-8, atol=1e-12)
+    np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
+    assert int(r['status'].item()) == 0 and ref.status == 0
+
+
+def test_training_set_too_large_for_the_fused_kernel_is_refused():
+    from safe_exploration_amd import _lib, problems
+    from safe_exploration_amd.cem_mpc import cem_rollout
+    spec = problems.pendulum(n_train=700)
+    ssm, env = problems.build(spec, DEV)
+    with pytest.raises(_lib.SxError, match='unsupported'):
+        cem_rollout(ssm, env, T(np.zeros((1, 2))), 3, actions=T(np.zeros((1, 16, 3, 1))))

@@ -28,6 +28,20 @@ def algorithmic_flops_per_particle_step(n_s, n_train, d_in):
 F64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; DESIGN.md "Roofline"
 
 
+def pmc_traffic(workload_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), or None.
+    bench.py cannot collect PMC counters itself; the number is only reported for the workload it was collected on."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
+            d = json.load(f)
+        if d.get('workload') == workload_key:
+            return d['hbm_traffic_bytes_per_launch']['cem_rollout_kernel<2,1>']
+    except Exception:
+        pass
+    return None
+
+
+
 def cpu_baseline(spec, horizon, particles, elites, budget_s=12.0, max_iters=8):
     """The numpy oracle (a port of the reference's arithmetic) on the host cores: a bounded sample of the workload."""
     import numpy as np
@@ -140,7 +154,10 @@ def main():
             'particle_rollouts_per_s': total_particles * iters * args.steps / elapsed,
             'device_status': status_word, 'solution_found': bool(ok[0].item()),
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / F64_MATRIX_PEAK_TFLOPS, 'traffic': None, 'kernel': 'cem_rollout_kernel<2,1>',
+                         'frac': achieved / F64_MATRIX_PEAK_TFLOPS,
+                         'traffic': pmc_traffic(f'cfg2 pendulum N_train={args.n_train} H={H} P={P}'),
+                         'traffic_unit': 'B/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.json)',
+                         'kernel': 'cem_rollout_kernel<2,1>',
                          'avg_launch_us': avg_rollout_s * 1e6, 'launches_timed': len(rollout_ms),
                          'algorithmic_flops_per_launch': flops_unit * P * H},
         }

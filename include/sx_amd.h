@@ -155,8 +155,8 @@ int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, in
 /* Ranking + elite refit for E problems, one workgroup each.
  * Candidates c = 0..P-1 of problem e have con = con_cost[(e*P+c)*cost_stride], obj likewise, and an action row of
  * `row_len` doubles at actions + (e*P+c)*act_stride.  Order: lexicographic (con, obj, c); NaN sorts last.
- *   elite_idx  dev int32 [E x k]            sorted elite indices (may be NULL)
- *   elite_rows dev [E x k x (2 + row_len)]  [con, obj, actions...] of the elites, sorted (may be NULL) -- the buffer
+ *   elite_idx  dev int32 [E x k]            elite indices: the best first, the others in a deterministic but unspecified order (may be NULL)
+ *   elite_rows dev [E x k x (2 + row_len)]  [con, obj, actions...] of the elites, same order (may be NULL) -- the buffer
  *                                           that is all-reduced across GPUs
  *   mean, std  dev [E x row_len]            refit (unbiased std; 0 when k == 1)  (may be NULL: no refit)
  *   best       dev [E x row_len]            first-ranked action sequence (may be NULL)

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 //   2. MSB-first radix select of the k-th key, 8 bits per pass: wave-aggregated LDS histogram (one atomic per wave when
 //      all lanes agree -- the common case in the high bytes), bin scan by one wave, early exit as soon as the bin
 //      holding the k-th key is wholly selected;
-//   3. ballot compaction in index order (ties broken by the lower index), bitonic sort of the k survivors in LDS;
+//   3. ballot compaction in index order (ties broken by the lower index); the best survivor is moved to the front,
+//      the others stay where the compaction put them (nothing downstream needs them sorted);
 //   4. refit: mean / unbiased std over the elites, rows spread over the whole workgroup.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRankThreads = 1024;
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     __shared__ double red[kRankThreads];
     __shared__ double col_mean[256];
     __shared__ int wave_cnt[kRankWaves][2];
+    __shared__ unsigned long long red_u64[kRankWaves], red_lo[kRankWaves];
     __shared__ int sh_digit, sh_need, sh_done;
 
     const int e = blockIdx.x;
@@ -570,12 +572,49 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         }
     }
 
+#ifdef SX_STAMPS
+    const unsigned long long ts0 = stamp();
+#endif
     // ---- radix select ----
     unsigned long long ph = 0, pl = 0;   // prefix of the k-th key found so far (uniform)
     unsigned long long mh = 0, ml = 0;   // mask of the prefix bits
     int need = k;                        // rank of the k-th key among the candidates matching the prefix
     bool done = false;
-    for (int pass = 0; pass < 16 && !done; ++pass) {
+    int first_pass = 0;
+    {
+        // Shortcut for the constraint word: constraint costs take few values (0 for every feasible particle).  If at
+        // least k candidates share the SMALLEST one, the k-th key has that high word and its eight passes are skipped.
+        unsigned long long mn = ~0ull;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) mn = kh[s] < mn ? kh[s] : mn;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(mn, off);
+            mn = o < mn ? o : mn;
+        }
+        if (lane == 0) red_u64[wave] = mn;
+        __syncthreads();
+        mn = red_u64[0];
+#pragma unroll
+        for (int w = 1; w < kRankWaves; ++w) mn = red_u64[w] < mn ? red_u64[w] : mn;
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) cnt += (s * kRankThreads + tid < P && kh[s] == mn) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane == 0) wave_cnt[wave][0] = cnt;
+        __syncthreads();
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < kRankWaves; ++w) total += wave_cnt[w][0];
+        __syncthreads();
+        if (total >= k) {
+            ph = mn;
+            mh = ~0ull;
+            first_pass = 8;
+        }
+    }
+    for (int pass = first_pass; pass < 16 && !done; ++pass) {
         const int shift = 56 - 8 * (pass & 7);
         const bool in_hi = pass < 8;
         if (tid < 256) hist[tid] = 0;
@@ -622,6 +661,9 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         need = sh_need;
         done = sh_done != 0;
     }
+#ifdef SX_STAMPS
+    const unsigned long long ts1 = stamp();
+#endif
     // Candidates whose masked key is below the prefix are selected; of those equal to it, the first `need` in index
     // order (all of them after an early exit).
     const int n_less_total = k - need;
@@ -663,32 +705,43 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         base_tie += tot_tie;
         __syncthreads();
     }
-    // ---- bitonic sort of the k selected entries by (hi, lo, idx); pad to a power of two with +inf keys ----
-    int n2 = 1;
-    while (n2 < k) n2 <<= 1;
-    for (int i = k + tid; i < n2; i += kRankThreads) {
-        sel_hi[i] = ~0ull;
-        sel_lo[i] = ~0ull;
-        sel_idx[i] = 0x7fffffff;
-    }
-    __syncthreads();
-    for (int size = 2; size <= n2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (n2 >> 1); i += kRankThreads) {
-                const int lo = 2 * i - (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool asc = ((lo & size) == 0);
-                const unsigned long long ah = sel_hi[lo], al = sel_lo[lo], bh = sel_hi[hi], bl = sel_lo[hi];
-                const int ai = sel_idx[lo], bi = sel_idx[hi];
-                const bool a_gt_b = (ah > bh) || (ah == bh && (al > bl || (al == bl && ai > bi)));
-                if (a_gt_b == asc) {
-                    sel_hi[lo] = bh; sel_lo[lo] = bl; sel_idx[lo] = bi;
-                    sel_hi[hi] = ah; sel_lo[hi] = al; sel_idx[hi] = ai;
-                }
-            }
-            __syncthreads();
+#ifdef SX_STAMPS
+    const unsigned long long ts2 = stamp();
+#endif
+    // ---- the elites stay where the compaction put them; only the best one is moved to the front ----
+    {
+        unsigned long long bh = ~0ull, bl = ~0ull;
+        int bi = 0x7fffffff, bslot = 0;
+        for (int i = tid; i < k; i += kRankThreads) {
+            const unsigned long long h = sel_hi[i], l = sel_lo[i];
+            const int ix = sel_idx[i];
+            if (h < bh || (h == bh && (l < bl || (l == bl && ix < bi)))) { bh = h; bl = l; bi = ix; bslot = i; }
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long oh = __shfl_xor(bh, off), ol = __shfl_xor(bl, off);
+            const int oi = __shfl_xor(bi, off), os = __shfl_xor(bslot, off);
+            if (oh < bh || (oh == bh && (ol < bl || (ol == bl && oi < bi)))) { bh = oh; bl = ol; bi = oi; bslot = os; }
+        }
+        if (lane == 0) { red_u64[wave] = bh; red_lo[wave] = bl; wave_cnt[wave][0] = bi; wave_cnt[wave][1] = bslot; }
+        __syncthreads();
+        if (tid == 0) {
+            int best_w = 0;
+            for (int w = 1; w < kRankWaves; ++w) {
+                const unsigned long long oh = red_u64[w], ol = red_lo[w], ch = red_u64[best_w], cl = red_lo[best_w];
+                if (oh < ch || (oh == ch && (ol < cl || (ol == cl && wave_cnt[w][0] < wave_cnt[best_w][0])))) best_w = w;
+            }
+            const int s = wave_cnt[best_w][1];
+            const unsigned long long th = sel_hi[0], tl = sel_lo[0];
+            const int ti = sel_idx[0];
+            sel_hi[0] = sel_hi[s]; sel_lo[0] = sel_lo[s]; sel_idx[0] = sel_idx[s];
+            sel_hi[s] = th; sel_lo[s] = tl; sel_idx[s] = ti;
+        }
+        __syncthreads();
     }
+#ifdef SX_STAMPS
+    const unsigned long long ts3 = stamp();
+#endif
     // ---- outputs ----
     const int L = ra.row_len;
     if (ra.elite_idx)
@@ -747,6 +800,12 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             __syncthreads();
         }
     }
+#ifdef SX_STAMPS
+    const unsigned long long ts4 = stamp();
+    if (g_stamp_buf && tid == 0 && e == 0) {
+        g_stamp_buf[0] = ts1 - ts0; g_stamp_buf[1] = ts2 - ts1; g_stamp_buf[2] = ts3 - ts2; g_stamp_buf[3] = ts4 - ts3;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

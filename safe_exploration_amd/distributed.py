@@ -33,7 +33,7 @@ def rank_seed(seed: int, rank: int) -> int:
 
 
 def exchange_elite_rows(rows: Tensor, group=None) -> Tensor:
-    """rows [E x k x W] (this rank's sorted local elites) -> [E x G*k x W], rank-major, identical on every rank.
+    """rows [E x k x W] (this rank's local elites, best first) -> [E x G*k x W], rank-major, identical on every rank.
 
     One all-reduce(sum) over zero-padded slots.  Adding zeros is exact in IEEE arithmetic for finite values and keeps
     +-inf; a NaN cost stays NaN.  (-0.0 + 0.0 = +0.0 does not change any ordering or refit.)

@@ -31,7 +31,7 @@ def _worker(rank, port, P, k, L, out):
         act = rng.normal(size=(P, L))
         count, off = distributed.shard_particles(P, WORLD, rank)
         idx = ocem.rank(con[off:off + count], obj[off:off + count], k) + off       # local elites (the kernel's job)
-        rows = np.concatenate((con[idx, None], obj[idx, None], act[idx]), axis=1)   # [k x (2 + L)], sorted
+        rows = np.concatenate((con[idx, None], obj[idx, None], act[idx]), axis=1)   # [k x (2 + L)]
         cand = distributed.exchange_elite_rows(torch.tensor(rows[None]), dist.group.WORLD)[0].numpy()
         assert cand.shape == (WORLD * k, 2 + L)
         np.testing.assert_array_equal(cand[rank * k:(rank + 1) * k], rows)         # own slot untouched

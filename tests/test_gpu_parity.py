@@ -190,7 +190,10 @@ def test_rank_refit_vs_oracle(P, k, L):
     out = cem_rank_refit(T(con), T(obj), T(act), k, want_rows=True)
     for e in range(E):
         idx = ocem.rank(con[e], obj[e], k)
-        np.testing.assert_array_equal(out['elite_idx'][e].cpu().numpy(), idx)
+        got = out['elite_idx'][e].cpu().numpy()
+        assert got[0] == idx[0]                                      # the best first ...
+        np.testing.assert_array_equal(np.sort(got), np.sort(idx))    # ... then the same elite set (order unspecified)
+        idx = got
         m, s = ocem.refit(act[e][idx])
         np.testing.assert_allclose(out['mean'][e].cpu().numpy(), m, rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(out['std'][e].cpu().numpy(), s, rtol=1e-12, atol=1e-14)

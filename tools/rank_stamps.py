@@ -1,0 +1,21 @@
+"""Diagnostic (SX_STAMPS build): cycle shares of the rank/refit kernel's sections."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from safe_exploration_amd import _lib
+from safe_exploration_amd.cem_mpc import cem_rank_refit
+dev = torch.device('cuda:0')
+P, k, L = int(os.environ.get('P', 4096)), int(os.environ.get('K', 409)), 15
+buf = torch.zeros(8, dtype=torch.int64, device=dev)
+lib = _lib.lib()
+lib.sx_debug_set_stamps.argtypes = [ctypes.c_void_p]
+assert lib.sx_debug_set_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
+g = torch.Generator(device=dev); g.manual_seed(0)
+for feas in (0.5, 0.02):
+    con = (torch.rand((1, P), device=dev, generator=g, dtype=torch.float64) > feas).double() * 10
+    obj = torch.randn((1, P), device=dev, generator=g, dtype=torch.float64)
+    act = torch.randn((1, P, L), device=dev, generator=g, dtype=torch.float64)
+    for _ in range(3):
+        cem_rank_refit(con, obj, act, k)
+    torch.cuda.synchronize()
+    print(f'feasible fraction {feas}: select/compact/sort/output+refit cycles =', buf[:4].tolist())

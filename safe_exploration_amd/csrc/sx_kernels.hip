@@ -582,36 +582,47 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     bool done = false;
     int first_pass = 0;
     {
-        // Shortcut for the constraint word: constraint costs take few values (0 for every feasible particle).  If at
-        // least k candidates share the SMALLEST one, the k-th key has that high word and its eight passes are skipped.
-        unsigned long long mn = ~0ull;
+        // The constraint word takes few distinct values (0 for every feasible particle, then 3 a + 10 b), so its
+        // k-th smallest value is found by walking up the distinct values: one (min, multiplicity) reduction per value,
+        // at most 8 of them, instead of eight radix passes.  (Beyond 8 the general passes below take over.)
+        unsigned long long floor_key = 0;  // only keys >= floor_key are still in play
+        int acc = 0;                       // candidates below floor_key
+        for (int it = 0; it < 8; ++it) {
+            unsigned long long mn = ~0ull;
+            int cnt = 0;
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) mn = kh[s] < mn ? kh[s] : mn;
+            for (int s = 0; s < SLOTS; ++s) {
+                const bool in_play = (s * kRankThreads + tid < P) && kh[s] >= floor_key;
+                if (in_play) {
+                    if (kh[s] < mn) { mn = kh[s]; cnt = 1; } else if (kh[s] == mn) { ++cnt; }
+                }
+            }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(mn, off);
-            mn = o < mn ? o : mn;
-        }
-        if (lane == 0) red_u64[wave] = mn;
-        __syncthreads();
-        mn = red_u64[0];
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long om = __shfl_xor(mn, off);
+                const int oc = __shfl_xor(cnt, off);
+                if (om < mn) { mn = om; cnt = oc; } else if (om == mn) { cnt += oc; }
+            }
+            if (lane == 0) { red_u64[wave] = mn; wave_cnt[wave][0] = cnt; }
+            __syncthreads();
+            mn = red_u64[0];
+            cnt = wave_cnt[0][0];
 #pragma unroll
-        for (int w = 1; w < kRankWaves; ++w) mn = red_u64[w] < mn ? red_u64[w] : mn;
-        int cnt = 0;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) cnt += (s * kRankThreads + tid < P && kh[s] == mn) ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-        if (lane == 0) wave_cnt[wave][0] = cnt;
-        __syncthreads();
-        int total = 0;
-#pragma unroll
-        for (int w = 0; w < kRankWaves; ++w) total += wave_cnt[w][0];
-        __syncthreads();
-        if (total >= k) {
-            ph = mn;
-            mh = ~0ull;
-            first_pass = 8;
+            for (int w = 1; w < kRankWaves; ++w) {
+                const unsigned long long om = red_u64[w];
+                const int oc = wave_cnt[w][0];
+                if (om < mn) { mn = om; cnt = oc; } else if (om == mn) { cnt += oc; }
+            }
+            __syncthreads();
+            if (acc + cnt >= k) {   // the k-th key has this constraint word
+                ph = mn;
+                mh = ~0ull;
+                need = k - acc;
+                first_pass = 8;
+                break;
+            }
+            acc += cnt;
+            floor_key = mn + 1;
         }
     }
     for (int pass = first_pass; pass < 16 && !done; ++pass) {

@@ -146,11 +146,19 @@ int sx_polytope_distance(const sx_env* env, int P, const double* p, const double
  *   sigma   dev [E x P x H x n_s] | NULL
  *   obj_cost, con_cost dev [E x P]     summed objective / constraint cost
  *   status  dev int32                  OR of SX_STATUS_*
+ *   workspace dev, sx_cem_rollout_workspace_bytes() bytes (may be NULL when that is 0): training sets whose Kstar tile does
+ *                                      not fit in LDS (config 4: N = 2000) take the three-launch-per-step path and keep
+ *                                      Kstar, partial sums and particle state there
  * Replaces: the H sequential DynamicsFunc callbacks + per-trajectory Constraint calls the optimiser makes per
  * iteration (safempc_cem.py:102-156,288-312; call sites of the absent constrained-cem-mpc). */
 int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
                    const double* mean, const double* std, const double* noise, double* actions, double* traj,
-                   double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream);
+                   double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
+/* Bytes of workspace sx_cem_rollout needs for this model and problem size: 0 = the fused single-launch path applies;
+ * < 0 = bad arguments. */
+int64_t sx_cem_rollout_workspace_bytes(const sx_gp_model* model, int E, int P, int H);
 
 /* Ranking + elite refit for E problems, one workgroup each.
  * Candidates c = 0..P-1 of problem e have con = con_cost[(e*P+c)*cost_stride], obj likewise, and an action row of

@@ -50,7 +50,9 @@ SIGNATURES = {
     'sx_onestep_reach': (c_int, [POINTER(SxEnv), c_int] + [c_void_p] * 11),
     'sx_polytope_distance': (c_int, [POINTER(SxEnv), c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p,
                                      c_void_p]),
-    'sx_cem_rollout': (c_int, [POINTER(SxGpModel), POINTER(SxEnv), c_int, c_int, c_int] + [c_void_p] * 12),
+    'sx_cem_rollout': (c_int, [POINTER(SxGpModel), POINTER(SxEnv), c_int, c_int, c_int] + [c_void_p] * 12
+                       + [c_int64, c_void_p]),
+    'sx_cem_rollout_workspace_bytes': (c_int64, [POINTER(SxGpModel), c_int, c_int, c_int]),
     'sx_cem_rank_refit': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64]
                           + [c_void_p] * 7),
 }

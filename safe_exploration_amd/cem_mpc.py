@@ -58,10 +58,15 @@ def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, act
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
     model = ssm.device_model
-    _lib.check(_lib.lib().sx_cem_rollout(ctypes.byref(model), ctypes.byref(env), E, P, horizon, _lib.ptr(x0.contiguous()),
-                                         _lib.ptr(q0), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(noise),
-                                         _lib.ptr(actions), _lib.ptr(traj), _lib.ptr(sigma), _lib.ptr(obj),
-                                         _lib.ptr(con), _lib.ptr(status), _lib.stream_ptr(dev)), 'sx_cem_rollout')
+    lib = _lib.lib()
+    ws_bytes = int(lib.sx_cem_rollout_workspace_bytes(ctypes.byref(model), E, P, horizon))
+    if ws_bytes < 0:
+        raise _lib.SxError('sx_cem_rollout_workspace_bytes: bad arguments')
+    workspace = ssm.workspace(ws_bytes)   # None on the fused path; cached on the model otherwise
+    _lib.check(lib.sx_cem_rollout(ctypes.byref(model), ctypes.byref(env), E, P, horizon, _lib.ptr(x0.contiguous()),
+                                  _lib.ptr(q0), _lib.ptr(mean), _lib.ptr(std), _lib.ptr(noise), _lib.ptr(actions),
+                                  _lib.ptr(traj), _lib.ptr(sigma), _lib.ptr(obj), _lib.ptr(con), _lib.ptr(status),
+                                  _lib.ptr(workspace), ws_bytes, _lib.stream_ptr(dev)), 'sx_cem_rollout')
     return dict(actions=actions, obj_cost=obj, con_cost=con, traj=traj, sigma=sigma, status=status)
 
 

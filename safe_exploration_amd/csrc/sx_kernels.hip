@@ -8,6 +8,7 @@
 #include "../../include/sx_amd.h"
 #include "sx_gp.hpp"
 #include "sx_reach.hpp"
+#include "sx_big.hpp"
 
 namespace sx {
 
@@ -966,11 +967,50 @@ static int launch_polytope(const sx_env* env, int P, const double* p, const doub
     return check_launch();
 }
 
+// does the fused kernel's LDS budget hold Kstar for this model?
+static bool fused_fits(int ns, int nu, int n_train, int n_pad, int H) {
+    const int nw = kRolloutThreads / 64;
+    const size_t lds = (gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw) + (size_t)SX_TILE * H * nu) * sizeof(double);
+    return lds <= kMaxLdsBytes && (ns * (n_pad >> 4) + nw - 1) / nw <= 64;
+}
+
 template <int NS, int NU>
-static int launch_rollout(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, hipStream_t stream) {
+static int launch_rollout_big(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, double* workspace,
+                              int64_t workspace_bytes, hipStream_t stream) {
+    constexpr int D = NS + NU;
+    auto gc = make_gp_const<NS, NU>(m, kRolloutThreads / 64);
+    ReachConst<NS, NU> rc;
+    if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
+    CostConst<SX_MAX_M, NS, NU> cc;
+    make_cost_const<NS, NU>(env, cc);
+    const int64_t total = (int64_t)rp.E * rp.P;
+    const int64_t p128 = (total + kBigTile - 1) / kBigTile * kBigTile;
+    BigWs ws = big_ws_layout(workspace, NS, D, m->n_pad, total);
+    if (!workspace || workspace_bytes < ws.total * (int64_t)sizeof(double)) return SX_ERR_ARG;
+    const int row_tiles = (m->n_pad + kBigTile - 1) / kBigTile;
+    BigInit bi{rp.x0, rp.q0, rp.mean, rp.std, rp.noise, rp.actions, rp.obj_cost, rp.con_cost, rp.P, rp.H};
+    hipLaunchKernelGGL((init_big_kernel<NS, NU>), dim3((unsigned)((p128 + 255) / 256)), dim3(256), 0, stream, bi, ws, total,
+                       p128);
+    for (int t = 0; t < rp.H; ++t) {
+        hipLaunchKernelGGL((kstar_big_kernel<NS, D>), dim3((unsigned)(p128 / 16), (unsigned)((m->n_pad + 255) / 256)),
+                           dim3(256), 0, stream, gc, ws);
+        hipLaunchKernelGGL((trmm_reduce_kernel<NS, D>), dim3((unsigned)(p128 / kBigTile), (unsigned)row_tiles, NS),
+                           dim3(kBigThreads), 0, stream, gc, ws, p128);
+        BigStep bs{rp.actions, rp.traj, rp.sigma, rp.obj_cost, rp.con_cost, rp.status, rp.H, t, row_tiles * 2,
+                   (t > 0 || rp.q0 != nullptr) ? 1 : 0};
+        hipLaunchKernelGGL((step_big_kernel<NS, NU>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0, stream, gc, rc, cc, bs,
+                           ws, total, p128);
+    }
+    return check_launch();
+}
+
+template <int NS, int NU>
+static int launch_rollout(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, double* workspace,
+                          int64_t workspace_bytes, hipStream_t stream) {
+    if (!fused_fits(NS, NU, m->n_train, m->n_pad, rp.H))
+        return launch_rollout_big<NS, NU>(m, env, rp, workspace, workspace_bytes, stream);
     const int nw = kRolloutThreads / 64;
     auto gc = make_gp_const<NS, NU>(m, nw);
-    if ((NS * (m->n_pad >> 4) + nw - 1) / nw > 64) return SX_ERR_UNSUPPORTED;
     ReachConst<NS, NU> rc;
     if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
     CostConst<SX_MAX_M, NS, NU> cc;
@@ -1052,7 +1092,7 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
         return SX_ERR_ARG;
     const int D = model->n_s + model->n_u;
     model->n_pad = sx::gp_n_pad(model->n_train, D);
-    if ((model->n_s * (model->n_pad >> 4) + SX_WAVES - 1) / SX_WAVES > 64) return SX_ERR_UNSUPPORTED;
+    const bool has_tab = (model->n_s * (model->n_pad >> 4) + SX_WAVES - 1) / SX_WAVES <= 64;  // else: large-N path only
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = sx::a_pack_doubles(model->n_s, model->n_pad);
     int grid = (int)((total + 255) / 256);
@@ -1062,9 +1102,10 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
     for (int i = 0; i < model->n_s * D; ++i) args.inv_ls2[i] = model->inv_ls2[i];
     hipLaunchKernelGGL(sx::pack_a_kernel, dim3(grid), dim3(256), 0, s, linv, alpha, model->x_train, args, model->n_s, D,
                        model->n_train, model->n_pad, const_cast<double*>(model->a_pack));
-    hipLaunchKernelGGL(sx::build_stage_tab_kernel, dim3(1), dim3(64 * SX_WAVES), 0, s,
-                       reinterpret_cast<int4*>(const_cast<int32_t*>(model->stage_tab)), model->n_s, model->n_train,
-                       model->n_pad, SX_WAVES, sx::gp_stage_cap(model->n_s, model->n_pad, SX_WAVES));
+    if (has_tab)
+        hipLaunchKernelGGL(sx::build_stage_tab_kernel, dim3(1), dim3(64 * SX_WAVES), 0, s,
+                           reinterpret_cast<int4*>(const_cast<int32_t*>(model->stage_tab)), model->n_s, model->n_train,
+                           model->n_pad, SX_WAVES, sx::gp_stage_cap(model->n_s, model->n_pad, SX_WAVES));
     return sx::check_launch();
 }
 
@@ -1103,16 +1144,25 @@ int sx_polytope_distance(const sx_env* env, int P, const double* p, const double
     }
 }
 
+int64_t sx_cem_rollout_workspace_bytes(const sx_gp_model* model, int E, int P, int H) {
+    if (!model || E <= 0 || P <= 0 || H <= 0) return -1;
+    if (sx::fused_fits(model->n_s, model->n_u, model->n_train, model->n_pad, H)) return 0;
+    return sx::big_ws_layout(nullptr, model->n_s, model->n_s + model->n_u, model->n_pad, (int64_t)E * P).total *
+           (int64_t)sizeof(double);
+}
+
 int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
                    const double* mean, const double* std, const double* noise, double* actions, double* traj,
-                   double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream) {
+                   double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
     if (!model || !env || !x0 || !actions || !obj_cost || !con_cost || !status) return SX_ERR_ARG;
     if (E <= 0 || P <= 0 || H <= 0) return SX_ERR_ARG;
     if (noise && (!mean || !std)) return SX_ERR_ARG;
     if (model->n_s != env->n_s || model->n_u != env->n_u) return SX_ERR_ARG;
     if (env->m <= 0 || env->m > SX_MAX_M) return SX_ERR_UNSUPPORTED;
     sx::RolloutPtrs rp{x0, q0, mean, std, noise, actions, traj, sigma, obj_cost, con_cost, status, E, P, H};
-#define CALL(NS, NU) sx::launch_rollout<NS, NU>(model, env, rp, (hipStream_t)stream)
+#define CALL(NS, NU) \
+    sx::launch_rollout<NS, NU>(model, env, rp, (double*)workspace, workspace_bytes, (hipStream_t)stream)
     SX_DISPATCH(model->n_s, model->n_u, CALL);
 #undef CALL
 }

@@ -47,6 +47,7 @@ class GpCemSSM(CemSSM):
         self._last_training_losses = []
         self._model: Optional[_lib.SxGpModel] = None
         self._buffers = ()  # keeps the device operands alive while the struct points at them
+        self._workspace: Optional[Tensor] = None
 
     # ---- hyper-parameters --------------------------------------------------------------------------------------
     @property
@@ -132,6 +133,14 @@ class GpCemSSM(CemSSM):
         """[n_s] information gain of the training inputs, per output (zeros without data)."""
         import numpy as np
         return np.zeros(self.num_states) if self._model is None else self._info_gain.copy()
+
+    def workspace(self, nbytes: int) -> Optional[Tensor]:
+        """Scratch for the large-training-set rollout path (grown on demand, reused across calls)."""
+        if nbytes <= 0:
+            return None
+        if self._workspace is None or self._workspace.numel() * 8 < nbytes:
+            self._workspace = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self._buffers[0].device)
+        return self._workspace
 
     @property
     def device_model(self) -> _lib.SxGpModel:

@@ -238,10 +238,39 @@ def test_cartpole_sized_rollout_vs_oracle():
     assert int(r['status'].item()) == 0 and ref.status == 0
 
 
-def test_training_set_too_large_for_the_fused_kernel_is_refused():
+@pytest.mark.parametrize('which,n_train,P,H', [('pendulum', 700, 150, 5), ('cartpole', 330, 200, 4)])
+def test_large_training_set_path_vs_oracle(which, n_train, P, H):
+    """Training sets whose Kstar tile does not fit in LDS take the three-launch-per-step path (config 4's shape in
+    small): same numbers as the oracle, and the same numbers as the fused path on a problem both can run."""
+    import ctypes
     from safe_exploration_amd import _lib, problems
     from safe_exploration_amd.cem_mpc import cem_rollout
-    spec = problems.pendulum(n_train=700)
+    spec = getattr(problems, which)(n_train=n_train, seed=5)
     ssm, env = problems.build(spec, DEV)
-    with pytest.raises(_lib.SxError, match='unsupported'):
-        cem_rollout(ssm, env, T(np.zeros((1, 2))), 3, actions=T(np.zeros((1, 16, 3, 1))))
+    assert _lib.lib().sx_cem_rollout_workspace_bytes(ctypes.byref(ssm.device_model), 1, P, H) > 0   # really the big path
+    gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+    rng = np.random.default_rng(3)
+    acts = rng.normal(0, 0.4 if which == 'cartpole' else 0.15, size=(P, H, spec.n_u))
+    x0 = rng.normal(0, 0.02, size=spec.n_s)
+    r = cem_rollout(ssm, env, T(x0[None]), H, actions=T(acts[None]), want_traj=True, want_sigma=True)
+    ref = ocem.rollout(problems.oracle_problem(spec, ocem), gp, x0, acts)
+    n_s = spec.n_s
+    traj = r['traj'][0].cpu().numpy()
+    np.testing.assert_allclose(traj[:, :, :n_s], ref.traj_p, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(traj[:, :, n_s:].reshape(P, H, n_s, n_s), ref.traj_q, rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(r['sigma'][0].cpu().numpy(), ref.sigma, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(r['obj_cost'][0].cpu().numpy(), ref.obj_cost, rtol=1e-7, atol=1e-12)
+    np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
+    assert int(r['status'].item()) == 0 and ref.status == 0
+    # sampling form (mean + std * noise) and two problems at once
+    mean = rng.normal(0, 0.05, size=(2, H, spec.n_u))
+    std = rng.uniform(0.05, 0.2, size=(2, H, spec.n_u))
+    noise = rng.normal(size=(2, 40, H, spec.n_u))
+    x2 = rng.normal(0, 0.02, size=(2, n_s))
+    r2 = cem_rollout(ssm, env, T(x2), H, mean=T(mean), std=T(std), noise=T(noise))
+    for e in range(2):
+        a_e = r2['actions'][e].cpu().numpy()
+        np.testing.assert_allclose(a_e, mean[e][None] + std[e][None] * noise[e], rtol=1e-13, atol=1e-16)
+        ref_e = ocem.rollout(problems.oracle_problem(spec, ocem), gp, x2[e], a_e)
+        np.testing.assert_allclose(r2['obj_cost'][e].cpu().numpy(), ref_e.obj_cost, rtol=1e-7, atol=1e-12)
+        np.testing.assert_array_equal(r2['con_cost'][e].cpu().numpy(), ref_e.con_cost)

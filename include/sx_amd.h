@@ -116,7 +116,10 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
  * Replaces: GpCemSSM.predict_with_jacobians / predict_without_jacobians / _predict (ssm_cem/gp_ssm_cem.py:59-94)
  * and compute_jacobian_fast (ssm_pytorch/utilities.py:54-85). */
 int sx_gp_predict(const sx_gp_model* model, const double* z, int P, double* mean, double* var, double* jac,
-                  void* stream);
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Bytes of workspace sx_gp_predict needs (0 while the training set fits the single-launch kernel; < 0 = bad arguments). */
+int64_t sx_gp_predict_workspace_bytes(const sx_gp_model* model, int P);
 
 /* One-step ellipsoidal reachability given the GP outputs at (p, u).
  * p dev [P x n_s]; Q dev [P x n_s x n_s] or NULL (point branch); u dev [P x n_u]; mean/var dev [P x n_s];

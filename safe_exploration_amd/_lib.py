@@ -46,7 +46,9 @@ SIGNATURES = {
     'sx_gp_pack_sizes': (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     'sx_gp_fit': (c_int, [POINTER(SxGpModel)] + [c_void_p] * 7),
     'sx_gp_pack': (c_int, [POINTER(SxGpModel), c_void_p, c_void_p, c_void_p]),
-    'sx_gp_predict': (c_int, [POINTER(SxGpModel), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'sx_gp_predict': (c_int, [POINTER(SxGpModel), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                              c_void_p]),
+    'sx_gp_predict_workspace_bytes': (c_int64, [POINTER(SxGpModel), c_int]),
     'sx_onestep_reach': (c_int, [POINTER(SxEnv), c_int] + [c_void_p] * 11),
     'sx_polytope_distance': (c_int, [POINTER(SxEnv), c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p,
                                      c_void_p]),

@@ -12,6 +12,8 @@
 
 namespace sx {
 
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
 #ifndef SX_ROLLOUT_THREADS
 #define SX_ROLLOUT_THREADS (64 * SX_WAVES)
 #endif
@@ -909,7 +911,6 @@ static int check_launch() {
     return SX_OK;
 }
 
-constexpr size_t kMaxLdsBytes = 160 * 1024;
 
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
@@ -924,12 +925,23 @@ static int allow_lds(K kernel, size_t bytes) {
     return SX_OK;
 }
 
+static bool predict_fits(int ns, int nu, int n_train, int n_pad) {
+    const int nw = kPredictThreads / 64;
+    return gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw) * sizeof(double) <= kMaxLdsBytes &&
+           (ns * (n_pad >> 4) + nw - 1) / nw <= 64;
+}
+
+template <int NS, int NU>
+static int launch_predict_big(const sx_gp_model* m, const double* z, int P, double* mean, double* var, double* jac,
+                              double* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 template <int NS, int NU>
 static int launch_predict(const sx_gp_model* m, const double* z, int P, double* mean, double* var, double* jac,
-                          hipStream_t stream) {
+                          double* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    if (!predict_fits(NS, NU, m->n_train, m->n_pad))
+        return launch_predict_big<NS, NU>(m, z, P, mean, var, jac, workspace, workspace_bytes, stream);
     const int nw = kPredictThreads / 64;
     auto gc = make_gp_const<NS, NU>(m, nw);
-    if ((NS * (m->n_pad >> 4) + nw - 1) / nw > 64) return SX_ERR_UNSUPPORTED;
     const size_t lds = gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) * sizeof(double);
     if (int rc = allow_lds(gp_predict_kernel<NS, NU>, lds)) return rc;
     const int tiles = (P + SX_TILE - 1) / SX_TILE;
@@ -964,6 +976,55 @@ static int launch_polytope(const sx_env* env, int P, const double* p, const doub
     const int threads = 64;
     hipLaunchKernelGGL((polytope_kernel<NS>), dim3((P + threads - 1) / threads), dim3(threads), 0, stream, pa, P,
                        c_safety, p, Q, d, inside);
+    return check_launch();
+}
+
+// ---- sx_gp_predict for training sets beyond the LDS budget: the same Kstar / triangular-product kernels, then collect ----
+template <int NS, int D>
+__global__ void predict_init_big_kernel(const double* __restrict__ z, int64_t P, int64_t p128, BigWs ws) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= p128 * D) return;
+    ws.zs[i] = (i < P * D) ? z[i] : 0.0;
+}
+
+template <int NS, int D>
+__global__ void predict_collect_big_kernel(GpConst<NS, D> gc, BigWs ws, int64_t P, int64_t p128, int row_parts,
+                                           double* __restrict__ mean, double* __restrict__ var, double* __restrict__ jac) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (g >= P) return;
+#pragma unroll
+    for (int d = 0; d < NS; ++d) {
+        double q = 0.0;
+        for (int r = 0; r < row_parts; ++r) q += ws.part[((int64_t)d * row_parts + r) * p128 + g];
+        var[g * NS + d] = (gc.outputscale[d] - q) + gc.noise[d];
+        const double m = ws.mj[((int64_t)d * (D + 1)) * p128 + g];
+        mean[g * NS + d] = m;
+        if (jac) {
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                jac[(g * NS + d) * D + j] =
+                    ws.mj[((int64_t)d * (D + 1) + 1 + j) * p128 + g] - ws.zs[g * D + j] * gc.inv_ls2[d * D + j] * m;
+        }
+    }
+}
+
+template <int NS, int NU>
+static int launch_predict_big(const sx_gp_model* m, const double* z, int P, double* mean, double* var, double* jac,
+                              double* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    constexpr int D = NS + NU;
+    auto gc = make_gp_const<NS, NU>(m, kPredictThreads / 64);
+    const int64_t p128 = ((int64_t)P + kBigTile - 1) / kBigTile * kBigTile;
+    BigWs ws = big_ws_layout(workspace, NS, D, m->n_pad, P);
+    if (!workspace || workspace_bytes < ws.total * (int64_t)sizeof(double)) return SX_ERR_ARG;
+    const int row_tiles = (m->n_pad + kBigTile - 1) / kBigTile;
+    hipLaunchKernelGGL((predict_init_big_kernel<NS, D>), dim3((unsigned)((p128 * D + 255) / 256)), dim3(256), 0, stream, z,
+                       (int64_t)P, p128, ws);
+    hipLaunchKernelGGL((kstar_big_kernel<NS, D>), dim3((unsigned)(p128 / 16), (unsigned)((m->n_pad + 255) / 256)), dim3(256),
+                       0, stream, gc, ws);
+    hipLaunchKernelGGL((trmm_reduce_kernel<NS, D>), dim3((unsigned)(p128 / kBigTile), (unsigned)row_tiles, NS),
+                       dim3(kBigThreads), 0, stream, gc, ws, p128);
+    hipLaunchKernelGGL((predict_collect_big_kernel<NS, D>), dim3((unsigned)((P + 63) / 64)), dim3(64), 0, stream, gc, ws,
+                       (int64_t)P, p128, row_tiles * 2, mean, var, jac);
     return check_launch();
 }
 
@@ -1109,11 +1170,18 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
     return sx::check_launch();
 }
 
+int64_t sx_gp_predict_workspace_bytes(const sx_gp_model* model, int P) {
+    if (!model || P < 0) return -1;
+    if (sx::predict_fits(model->n_s, model->n_u, model->n_train, model->n_pad)) return 0;
+    return sx::big_ws_layout(nullptr, model->n_s, model->n_s + model->n_u, model->n_pad, P).total * (int64_t)sizeof(double);
+}
+
 int sx_gp_predict(const sx_gp_model* model, const double* z, int P, double* mean, double* var, double* jac,
-                  void* stream) {
+                  void* workspace, int64_t workspace_bytes, void* stream) {
     if (!model || !z || !mean || !var || P < 0) return SX_ERR_ARG;
     if (P == 0) return SX_OK;
-#define CALL(NS, NU) sx::launch_predict<NS, NU>(model, z, P, mean, var, jac, (hipStream_t)stream)
+#define CALL(NS, NU) \
+    sx::launch_predict<NS, NU>(model, z, P, mean, var, jac, (double*)workspace, workspace_bytes, (hipStream_t)stream)
     SX_DISPATCH(model->n_s, model->n_u, CALL);
 #undef CALL
 }

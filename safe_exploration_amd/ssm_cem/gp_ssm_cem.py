@@ -192,8 +192,11 @@ class GpCemSSM(CemSSM):
             if jac is not None:
                 jac.zero_()
             return mean, var, jac
-        _lib.check(_lib.lib().sx_gp_predict(ctypes.byref(self._model), _lib.ptr(z), n, _lib.ptr(mean), _lib.ptr(var),
-                                            _lib.ptr(jac), _lib.stream_ptr(z.device)), 'sx_gp_predict')
+        lib = _lib.lib()
+        ws_bytes = int(lib.sx_gp_predict_workspace_bytes(ctypes.byref(self._model), n))
+        _lib.check(lib.sx_gp_predict(ctypes.byref(self._model), _lib.ptr(z), n, _lib.ptr(mean), _lib.ptr(var),
+                                     _lib.ptr(jac), _lib.ptr(self.workspace(ws_bytes)), ws_bytes,
+                                     _lib.stream_ptr(z.device)), 'sx_gp_predict')
         return mean, var, jac
 
     def predict_with_jacobians(self, states: Tensor, actions: Tensor) -> Tuple[Tensor, Tensor, Tensor]:

@@ -76,7 +76,7 @@ def test_argument_errors_without_a_gpu(lib):
     assert lib.sx_cem_rank_refit(1, 4, 8, 3, None, None, 1, None, 3, None, None, None, None, None, None, None) == _lib.SX_ERR_ARG
     assert lib.sx_onestep_reach(ctypes.byref(env), 4, None, None, None, None, None, None, None, None, None, None, None) \
         == _lib.SX_ERR_ARG
-    assert lib.sx_gp_predict(None, None, 1, None, None, None, None) == _lib.SX_ERR_ARG
+    assert lib.sx_gp_predict(None, None, 1, None, None, None, None, 0, None) == _lib.SX_ERR_ARG
 
 
 def test_missing_library_fails_loudly(monkeypatch):

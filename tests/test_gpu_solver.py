@@ -274,3 +274,49 @@ def test_large_training_set_path_vs_oracle(which, n_train, P, H):
         ref_e = ocem.rollout(problems.oracle_problem(spec, ocem), gp, x2[e], a_e)
         np.testing.assert_allclose(r2['obj_cost'][e].cpu().numpy(), ref_e.obj_cost, rtol=1e-7, atol=1e-12)
         np.testing.assert_array_equal(r2['con_cost'][e].cpu().numpy(), ref_e.con_cost)
+
+
+def test_gp_predict_large_training_set_vs_oracle():
+    from safe_exploration_amd import problems
+    spec = problems.pendulum(n_train=650, seed=9)
+    ssm, _ = problems.build(spec, DEV)
+    gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+    rng = np.random.default_rng(1)
+    for P in (1, 130, 300):
+        z = rng.uniform(-0.5, 0.5, size=(P, 3))
+        m, v, j = ssm.predict_with_jacobians(T(z[:, :2]), T(z[:, 2:]))
+        mo, vo, jo = gp.predict(z)
+        np.testing.assert_allclose(m.cpu().numpy(), mo, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(v.cpu().numpy(), vo, rtol=1e-7, atol=1e-11)
+        np.testing.assert_allclose(j.cpu().numpy(), jo, rtol=1e-8, atol=1e-10)
+        m2, v2 = ssm.predict_without_jacobians(T(z[:, :2]), T(z[:, 2:]))
+        assert torch.equal(m2, m) and torch.equal(v2, v)
+
+
+def test_config4_training_set_size():
+    """BASELINE config 4's GP (cart-pole, N_train = 2000) at a particle count the oracle finishes in seconds; at the
+    full 16 384 particles the same launch is checked through a size-independent property: identical action sequences
+    give identical particles, wherever they sit in the batch."""
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.cem_mpc import cem_rollout
+    spec = problems.cartpole(n_train=2000, seed=2)
+    ssm, env = problems.build(spec, DEV)
+    gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+    P, H = 48, 3
+    rng = np.random.default_rng(12)
+    acts = rng.normal(0, 0.5, size=(P, H, 1))
+    x0 = rng.normal(0, 0.02, size=4)
+    r = cem_rollout(ssm, env, T(x0[None]), H, actions=T(acts[None]), want_traj=True, want_sigma=True)
+    ref = ocem.rollout(problems.oracle_problem(spec, ocem), gp, x0, acts)
+    traj = r['traj'][0].cpu().numpy()
+    np.testing.assert_allclose(traj[:, :, :4], ref.traj_p, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(traj[:, :, 4:].reshape(P, H, 4, 4), ref.traj_q, rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(r['sigma'][0].cpu().numpy(), ref.sigma, rtol=1e-6, atol=1e-11)
+    np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
+    big_p = 16384
+    tiled = np.tile(acts, (big_p // P + 1, 1, 1))[:big_p]
+    rb = cem_rollout(ssm, env, T(x0[None]), H, actions=T(tiled[None]))
+    obj = rb['obj_cost'][0].cpu().numpy()
+    np.testing.assert_allclose(obj[:P], ref.obj_cost, rtol=1e-6, atol=1e-11)
+    assert (obj.reshape(-1)[:(big_p // P) * P].reshape(-1, P) == obj[:P][None]).all()     # bit-identical replicas
+    assert (rb['con_cost'][0].cpu().numpy()[:P] == ref.con_cost).all()

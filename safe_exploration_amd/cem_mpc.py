@@ -164,6 +164,11 @@ class FusedCemMpc:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         history: List[Rollouts] = []
         out = None
+        if noise is None and 'sample_noise' not in vars(self):
+            # one generator launch for the whole solve instead of one per iteration (a test that patches sample_noise
+            # on the instance still gets its per-iteration calls)
+            noise = torch.randn((self._num_iterations, E, self._local_rollouts, H, n_u), dtype=torch.float64,
+                                device=self._device, generator=self._gen)
         for it in range(self._num_iterations):
             eps = noise[it] if noise is not None else self.sample_noise(E)
             if self.rollout_events is not None:

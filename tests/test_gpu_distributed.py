@@ -1,0 +1,58 @@
+"""GPU, 2 processes sharing the one card, gloo group: the sharded solve end to end (local rollout on the HIP path, local
+elite rows, one all-reduce, global ranking on every rank) equals the oracle's solve over the union of the particles,
+bit-identically on both ranks.  (The driver's multi-GPU run uses the same code with backend nccl = RCCL.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+WORLD = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from oracle import cem as ocem
+        from oracle.gp import ExactGP
+        from safe_exploration_amd import problems
+        from safe_exploration_amd.cem_mpc import FusedCemMpc
+        dev = torch.device('cuda:0')
+        spec = problems.pendulum(n_train=90, seed=4, obj_mode=1)
+        ssm, env = problems.build(spec, dev)
+        P, H, k, iters = 192, 5, 16, 3            # global particle count, sharded 96 + 96
+        rng = np.random.default_rng(33)
+        noise = rng.normal(size=(iters, P, H, 1))   # the global draws, identical on both ranks
+        x0 = np.array([0.015, -0.02])
+        mpc = FusedCemMpc(ssm, env, H, P, k, iters, device=dev, init_std=0.2, process_group=dist.group.WORLD)
+        lo, hi = rank * P // WORLD, (rank + 1) * P // WORLD
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+        best, ok, _, status = mpc.solve(t(x0[None]), noise=t(noise[:, None, lo:hi]))
+        torch.cuda.synchronize()
+        gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+        ref, _ = ocem.cem_solve(problems.oracle_problem(spec, ocem), gp, x0, noise, k, init_std=np.full((H, 1), 0.2))
+        assert int(status.item()) == 0 and ref is not None and int(ok[0]) == 1
+        np.testing.assert_allclose(best[0].cpu().numpy(), ref, rtol=0, atol=1e-9)
+        out[rank] = best[0].cpu().numpy().tobytes()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_solve_two_ranks():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(port, out), nprocs=WORLD, join=True)
+        assert len(out) == WORLD and out[0] == out[1]        # every rank holds the same bytes

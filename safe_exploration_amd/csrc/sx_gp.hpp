@@ -104,25 +104,40 @@ struct GpTileLds {
     }
 };
 
-// MFMA work decomposition shared by host (LDS sizing) and device (stream construction).
+// MFMA work decomposition shared by host (table sizing) and device (stream construction).
 //   task j : row-block rb = nrb - 1 - j / NS of output d = j % NS (descending cost)       2 (rb + 1) fragment pairs
-// snake-assigned to the waves by cost; every task is cut into stages of 2 pairs (4 MFMAs; pair counts are even).
-__host__ __device__ inline int gp_task_of(int round, int wave, int nw) {
-    return round * nw + ((round & 1) ? (nw - 1 - wave) : wave);
-}
+// Every task is cut into stages of 2 pairs (4 MFMAs; pair counts are even).  Tasks go to the waves by greedy
+// longest-processing-time assignment.  (Handing the second-dispatched half of the workgroup less work does not help:
+// it loses the arbitration for its SIMD's matrix pipe, but the phase ends when the SIMD's TOTAL is done -- measured.)
 __host__ __device__ inline int gp_task_pairs(int j, int ns, int nrb) { return 2 * (nrb - j / ns); }
 constexpr int kStagePad = 8;  // dummy descriptors behind a wave's stream: prefetches past the end stay in bounds
-inline int gp_stage_cap(int ns, int n_pad, int nw) {
-    const int nrb = n_pad >> 4, ntask = ns * nrb, rounds = (ntask + nw - 1) / nw;
-    int cap = 0;
-    for (int w = 0; w < nw; ++w) {
-        int n = 0;
-        for (int r = 0; r < rounds; ++r) {
-            const int j = gp_task_of(r, w, nw);
-            if (j < ntask) n += gp_task_pairs(j, ns, nrb) / 2;
+constexpr int kMaxWaves = 16;
+__host__ __device__ inline int gp_wave_speed(int, int) { return 100; }
+// Replays the assignment; returns the wave of task `upto` and leaves the per-wave stage counts before it in `load`.
+__host__ __device__ inline int gp_assign(int ns, int nrb, int nw, int upto, int* load) {
+    for (int w = 0; w < nw; ++w) load[w] = 0;
+    int wave = 0;
+    for (int j = 0; j <= upto; ++j) {
+        const int cost = gp_task_pairs(j, ns, nrb) / 2;
+        long best = -1;
+        for (int w = 0; w < nw; ++w) {
+            const long finish = (long)(load[w] + cost) * 1000 / gp_wave_speed(w, nw);
+            if (best < 0 || finish < best) {
+                best = finish;
+                wave = w;
+            }
         }
-        cap = n > cap ? n : cap;
+        if (j < upto) load[wave] += cost;
     }
+    return wave;
+}
+inline int gp_stage_cap(int ns, int n_pad, int nw) {
+    const int nrb = n_pad >> 4, ntask = ns * nrb;
+    int load[kMaxWaves];
+    const int w_last = gp_assign(ns, nrb, nw, ntask - 1, load);
+    load[w_last] += gp_task_pairs(ntask - 1, ns, nrb) / 2;
+    int cap = 0;
+    for (int w = 0; w < nw; ++w) cap = load[w] > cap ? load[w] : cap;
     return cap + kStagePad;
 }
 
@@ -200,38 +215,41 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
 // per-lane offset, and the only vector instruction per stage besides loads and MFMAs is the B address add.
 constexpr int kStageLast = 2, kStageExtra = 4;
 
-// one workgroup of nw waves; tab = [nw] headers, then [nw][stage_cap] descriptors
+// one thread per wave (warm path): replay the assignment and write that wave's stream.
+// tab = [nw] headers {stage count}, then [nw][stage_cap] descriptors
 __device__ __forceinline__ void gp_build_stage_tab(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap,
-                                                   int wave, int lane) {
+                                                   int wave) {
     const int nrb = n_pad >> 4;
     const int ntask = ns * nrb;
     const int wpo = (int)w_pairs_per_output(nrb);
-    // lane = round; (host guarantees rounds <= 64)
-    const int rounds = (ntask + nw - 1) / nw;
-    const int j = gp_task_of(lane, wave, nw);
-    const bool has = lane < rounds && j < ntask;
-    const int npairs = has ? gp_task_pairs(j, ns, nrb) : 0;
-    const int mine = npairs >> 1;
-    int incl = mine;  // inclusive scan over the wave
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-    }
-    const int total = __shfl(incl, 63);
     int4* out = tab + nw + (size_t)wave * stage_cap;
-    if (has) {
+    int load[kMaxWaves];
+    for (int w = 0; w < nw; ++w) load[w] = 0;
+    int pos = 0;
+    for (int j = 0; j < ntask; ++j) {
+        const int npairs = gp_task_pairs(j, ns, nrb);
+        const int cost = npairs / 2;
+        long best = -1;
+        int target = 0;
+        for (int w = 0; w < nw; ++w) {
+            const long finish = (long)(load[w] + cost) * 1000 / gp_wave_speed(w, nw);
+            if (best < 0 || finish < best) {
+                best = finish;
+                target = w;
+            }
+        }
+        load[target] += cost;
+        if (target != wave) continue;
         const int rb = nrb - 1 - j / ns;
         const int d = j % ns;
         const int a0 = d * wpo + rb * (rb + 1);
         const int extra = (16 * rb + 15 >= n_train) ? kStageExtra : 0;  // block holds mean/Jacobian (or padding) rows
-        int pos = incl - mine;
         for (int q = 0; q < npairs; q += 2, ++pos)
             out[pos] = int4{a0 + q, d * n_pad * 8 + q * 64, d | (rb << 8), extra | ((q + 2 >= npairs) ? kStageLast : 0)};
     }
     // dummy descriptors (valid addresses, never computed on) behind the stream
-    if (lane < kStagePad) out[total + lane] = int4{0, 0, 0, 0};
-    if (lane == 0) tab[wave] = int4{total, 0, 0, 0};
+    for (int i = 0; i < kStagePad; ++i) out[pos + i] = int4{0, 0, 0, 0};
+    tab[wave] = int4{pos, 0, 0, 0};
 }
 
 struct MfmaStage {

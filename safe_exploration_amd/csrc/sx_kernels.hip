@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kFitThreads) void gp_fit_kernel(FitArgs fa) {
 }
 
 __global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap) {
-    gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x >> 6, threadIdx.x & 63);
+    if ((int)threadIdx.x < nw) gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -927,8 +927,7 @@ static int allow_lds(K kernel, size_t bytes) {
 
 static bool predict_fits(int ns, int nu, int n_train, int n_pad) {
     const int nw = kPredictThreads / 64;
-    return gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw) * sizeof(double) <= kMaxLdsBytes &&
-           (ns * (n_pad >> 4) + nw - 1) / nw <= 64;
+    return gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw) * sizeof(double) <= kMaxLdsBytes && n_pad <= 1024;
 }
 
 template <int NS, int NU>
@@ -1032,7 +1031,7 @@ static int launch_predict_big(const sx_gp_model* m, const double* z, int P, doub
 static bool fused_fits(int ns, int nu, int n_train, int n_pad, int H) {
     const int nw = kRolloutThreads / 64;
     const size_t lds = (gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw) + (size_t)SX_TILE * H * nu) * sizeof(double);
-    return lds <= kMaxLdsBytes && (ns * (n_pad >> 4) + nw - 1) / nw <= 64;
+    return lds <= kMaxLdsBytes && n_pad <= 1024;
 }
 
 template <int NS, int NU>
@@ -1153,7 +1152,7 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
         return SX_ERR_ARG;
     const int D = model->n_s + model->n_u;
     model->n_pad = sx::gp_n_pad(model->n_train, D);
-    const bool has_tab = (model->n_s * (model->n_pad >> 4) + SX_WAVES - 1) / SX_WAVES <= 64;  // else: large-N path only
+    const bool has_tab = model->n_pad <= 1024;  // beyond that only the large-training-set path runs (no stage table)
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = sx::a_pack_doubles(model->n_s, model->n_pad);
     int grid = (int)((total + 255) / 256);
@@ -1164,7 +1163,7 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
     hipLaunchKernelGGL(sx::pack_a_kernel, dim3(grid), dim3(256), 0, s, linv, alpha, model->x_train, args, model->n_s, D,
                        model->n_train, model->n_pad, const_cast<double*>(model->a_pack));
     if (has_tab)
-        hipLaunchKernelGGL(sx::build_stage_tab_kernel, dim3(1), dim3(64 * SX_WAVES), 0, s,
+        hipLaunchKernelGGL(sx::build_stage_tab_kernel, dim3(1), dim3(64), 0, s,
                            reinterpret_cast<int4*>(const_cast<int32_t*>(model->stage_tab)), model->n_s, model->n_train,
                            model->n_pad, SX_WAVES, sx::gp_stage_cap(model->n_s, model->n_pad, SX_WAVES));
     return sx::check_launch();

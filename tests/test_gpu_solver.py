@@ -320,3 +320,31 @@ def test_config4_training_set_size():
     np.testing.assert_allclose(obj[:P], ref.obj_cost, rtol=1e-6, atol=1e-11)
     assert (obj.reshape(-1)[:(big_p // P) * P].reshape(-1, P) == obj[:P][None]).all()     # bit-identical replicas
     assert (rb['con_cost'][0].cpu().numpy()[:P] == ref.con_cost).all()
+
+
+def test_numpy_state_space_model_adapter():
+    """StateSpaceModel.predict (numpy in / out) over the HIP GP == oracle; __call__ gives the 3-tuple the reference's
+    numpy reachability code unpacks (gp_reachability.py: `mu_0, sigm_0, jac_mu = ssm(x, u)`)."""
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+    from safe_exploration_amd.state_space_models import HipGpStateSpaceModel
+    rng = np.random.default_rng(6)
+    X = rng.uniform(-1, 1, size=(80, 5))
+    Y = np.stack([np.sin(X[:, 0]), X[:, 1] * 0.3, np.cos(X[:, 2]), X[:, 3] - X[:, 4]], 1) * 0.1
+    ls, s, nz = rng.uniform(0.8, 2.0, size=(4, 5)), rng.uniform(0.05, 0.2, size=4), np.full(4, 1e-3)
+    ssm = GpCemSSM(Conf(), 4, 1)
+    ssm.set_hyperparameters(ls, s, nz)
+    model = HipGpStateSpaceModel(ssm, DEV)
+    model.update_model(X[:50], Y[:50], replace_old=True)
+    model.update_model(X[50:], Y[50:], replace_old=False)            # merged
+    gp = ExactGP(X, Y, ls, s, nz)
+    z = rng.uniform(-1, 1, size=(9, 5))
+    m, v, j = model(z[:, :4], z[:, 4:])
+    mo, vo, jo = gp.predict(z)
+    assert isinstance(m, np.ndarray) and j.shape == (9, 4, 5)
+    np.testing.assert_allclose(m, mo, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(v, vo, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(j, jo, rtol=1e-9, atol=1e-12)
+    m2, v2 = model.predict(z[:1, :4], z[:1, 4:])
+    assert m2.shape == (1, 4) and np.array_equal(m2, m[:1])
+    with pytest.raises(NotImplementedError):
+        model.predict(z[:, :4], z[:, 4:], full_cov=True)

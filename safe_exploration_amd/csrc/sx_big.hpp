@@ -159,19 +159,32 @@ __global__ __launch_bounds__(kBigThreads) void trmm_reduce_kernel(GpConst<NS, D>
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
 
-    for (int q0 = 0; q0 < npairs; q0 += 2) {
-        // stage 8 row-blocks x 2 pairs of W and 8 particle tiles x 2 pairs of Kstar: 2 x 1024 v2d, 4 + 4 per thread
+    // Global -> register -> LDS staging, one chunk (2 fragment pairs = 16 k) ahead: the loads of chunk c + 1 are in
+    // flight while the 32 MFMAs per wave of chunk c run.  A chunk is 8 row-blocks x 2 pairs of W and 8 particle tiles
+    // x 2 pairs of Kstar: 2 x 1024 v2d, 4 + 4 per thread.
+    v2d ra[4], rb_[4];
+    auto fetch = [&](int q0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * kBigThreads + tid;   // 0 .. 1023
             const int blk = idx >> 7, pr = (idx >> 6) & 1, ln = idx & 63;
             const int rb = rb0 + blk, q = q0 + pr;
-            v2d a = v2d{0.0, 0.0};
-            if (rb < rb_end && q < 2 * (rb + 1)) a = apack[((int64_t)rb * (rb + 1) + q) * 64 + ln];
-            sA[blk][pr][ln] = a;
-            sB[blk][pr][ln] = ks[(int64_t)blk * tstride + (int64_t)q * 64 + ln];
+            ra[it] = v2d{0.0, 0.0};
+            if (rb < rb_end && q < 2 * (rb + 1)) ra[it] = apack[((int64_t)rb * (rb + 1) + q) * 64 + ln];
+            rb_[it] = ks[(int64_t)blk * tstride + (int64_t)q * 64 + ln];
+        }
+    };
+    fetch(0);
+    for (int q0 = 0; q0 < npairs; q0 += 2) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * kBigThreads + tid;
+            const int blk = idx >> 7, pr = (idx >> 6) & 1, ln = idx & 63;
+            sA[blk][pr][ln] = ra[it];
+            sB[blk][pr][ln] = rb_[it];
         }
         __syncthreads();
+        if (q0 + 2 < npairs) fetch(q0 + 2);
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
             v2d a[4], b[4];

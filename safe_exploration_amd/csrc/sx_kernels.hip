@@ -163,6 +163,79 @@ __global__ __launch_bounds__(kFitThreads) void gp_fit_kernel(FitArgs fa) {
     if (tid == 0) fa.logdet[d] = red[0];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_mll_grad: exact marginal log likelihood of output d and its gradient w.r.t. (lengthscale_d[0..D), outputscale_d,
+// noise_d), from the factorisation sx_gp_fit left behind:
+//   mll = -1/2 y.alpha - sum log diag L - N/2 log 2 pi,      d mll / d theta = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta),
+//   K^-1 = W^T W.   One workgroup per output; pair (i, j <= i) is handled by thread j (W rows are read coalesced).
+// ---------------------------------------------------------------------------------------------------------------
+struct MllArgs {
+    double inv_ls2[SX_MAX_NS * SX_MAX_D];
+    double outputscale[SX_MAX_NS];
+    double noise[SX_MAX_NS];
+    const double* x;
+    const double* y;
+    const double* linv;
+    const double* alpha;
+    const double* logdet;
+    double* mll;    // [n_s]
+    double* grad;   // [n_s x (D + 2)]
+    int n, D, n_s;
+};
+
+__global__ __launch_bounds__(kFitThreads) void gp_mll_grad_kernel(MllArgs ma) {
+    __shared__ double red[kFitThreads];
+    const int d = blockIdx.x, tid = threadIdx.x, n = ma.n, D = ma.D;
+    const double* W = ma.linv + (size_t)d * n * n;
+    const double* al = ma.alpha + (size_t)d * n;
+    double acc[SX_MAX_D + 2];
+#pragma unroll
+    for (int c = 0; c < SX_MAX_D + 2; ++c) acc[c] = 0.0;
+    double ya = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double ai = al[i];
+        for (int j = tid; j <= i; j += kFitThreads) {
+            double kinv = 0.0;
+            for (int r = i; r < n; ++r) kinv += W[(size_t)r * n + i] * W[(size_t)r * n + j];
+            const double g = ai * al[j] - kinv;
+            double q = 0.0;
+            double dq[SX_MAX_D];
+            for (int c = 0; c < D; ++c) {
+                const double df = ma.x[(size_t)i * D + c] - ma.x[(size_t)j * D + c];
+                dq[c] = df * df * ma.inv_ls2[d * D + c];   // (x_ic - x_jc)^2 / l_c^2
+                q += dq[c];
+            }
+            const double kij = ma.outputscale[d] * exp(-0.5 * q);
+            const double w = (i == j) ? 0.5 : 1.0;         // 1/2 tr(...) over the symmetric pair
+            for (int c = 0; c < D; ++c) acc[c] += w * g * kij * dq[c];          // * 1 / l_c applied below
+            acc[D] += w * g * kij;                                              // * 1 / s applied below
+            if (i == j) acc[D + 1] += 0.5 * g;
+        }
+        if (i % kFitThreads == tid) ya += ma.y[(size_t)i * ma.n_s + d] * ai;
+    }
+    for (int c = 0; c < D + 3; ++c) {
+        double v = (c < D + 2) ? acc[c] : ya;
+        red[tid] = v;
+        __syncthreads();
+        for (int off = kFitThreads / 2; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double tot = red[0];
+            if (c < D)
+                ma.grad[d * (D + 2) + c] = tot * sqrt(ma.inv_ls2[d * D + c]);   // dK/dl_c = K (x_i - x_j)^2 / l_c^3
+            else if (c == D)
+                ma.grad[d * (D + 2) + D] = tot / ma.outputscale[d];
+            else if (c == D + 1)
+                ma.grad[d * (D + 2) + D + 1] = tot;
+            else
+                ma.mll[d] = -0.5 * tot - ma.logdet[d] - 0.5 * n * 1.8378770664093453;   // log(2 pi)
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap) {
     if ((int)threadIdx.x < nw) gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x);
 }
@@ -1143,6 +1216,33 @@ int sx_gp_fit(const sx_gp_model* model, const double* y_train, double* work, dou
     fa.D = D;
     fa.n_s = model->n_s;
     hipLaunchKernelGGL(sx::gp_fit_kernel, dim3(model->n_s), dim3(sx::kFitThreads), 0, (hipStream_t)stream, fa);
+    return sx::check_launch();
+}
+
+int sx_gp_mll_grad(const sx_gp_model* model, const double* y_train, const double* linv, const double* alpha,
+                   const double* logdet, double* mll, double* grad, void* stream) {
+    if (!model || !model->x_train || !y_train || !linv || !alpha || !logdet || !mll || !grad) return SX_ERR_ARG;
+    if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)
+        return SX_ERR_ARG;
+    sx::MllArgs ma;
+    std::memset(&ma, 0, sizeof(ma));
+    const int D = model->n_s + model->n_u;
+    for (int i = 0; i < model->n_s * D; ++i) ma.inv_ls2[i] = model->inv_ls2[i];
+    for (int i = 0; i < model->n_s; ++i) {
+        ma.outputscale[i] = model->outputscale[i];
+        ma.noise[i] = model->noise[i];
+    }
+    ma.x = model->x_train;
+    ma.y = y_train;
+    ma.linv = linv;
+    ma.alpha = alpha;
+    ma.logdet = logdet;
+    ma.mll = mll;
+    ma.grad = grad;
+    ma.n = model->n_train;
+    ma.D = D;
+    ma.n_s = model->n_s;
+    hipLaunchKernelGGL(sx::gp_mll_grad_kernel, dim3(model->n_s), dim3(sx::kFitThreads), 0, (hipStream_t)stream, ma);
     return sx::check_launch();
 }
 

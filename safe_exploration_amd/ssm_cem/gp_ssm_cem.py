@@ -13,7 +13,6 @@ Hyper-parameters follow gpytorch's parameterisation (softplus of a raw parameter
 1e-4 floor).  gpytorch is not available to check these defaults against: "parity unpinned" (DESIGN.md).
 """
 import ctypes
-import math
 from typing import Any, Dict, Optional, Tuple
 
 import torch
@@ -48,6 +47,7 @@ class GpCemSSM(CemSSM):
         self._model: Optional[_lib.SxGpModel] = None
         self._buffers = ()  # keeps the device operands alive while the struct points at them
         self._workspace: Optional[Tensor] = None
+        self._fit_ws = None
 
     # ---- hyper-parameters --------------------------------------------------------------------------------------
     @property
@@ -86,12 +86,28 @@ class GpCemSSM(CemSSM):
             self._update_model(self._x_train, self._y_train)
 
     # ---- model (re)build: the warm path ------------------------------------------------------------------------
-    def _kernel_matrices(self, x: Tensor, lengthscale: Tensor, outputscale: Tensor, noise: Tensor) -> Tensor:
-        """[n_s x N x N]  K_d + noise_d I."""
-        xs = x.unsqueeze(0) / lengthscale.unsqueeze(1)                      # [n_s x N x D]
-        sq = torch.cdist(xs, xs, compute_mode='donot_use_mm_for_euclid_dist').pow(2)
-        k = outputscale.view(-1, 1, 1) * torch.exp(-0.5 * sq)
-        return k + noise.view(-1, 1, 1) * torch.eye(x.size(0), dtype=x.dtype, device=x.device)
+    def _fit(self, x: Tensor, y: Tensor):
+        """sx_gp_fit for the current hyper-parameters.  Returns (model struct, linv, alpha, logdet); raises if the
+        kernel matrix is not positive definite."""
+        lib = _lib.lib()
+        dev = x.device
+        n_s, n_u, n = self.num_states, self.num_actions, x.size(0)
+        m = _lib.SxGpModel()
+        m.n_s, m.n_u, m.n_train = n_s, n_u, n
+        _lib.fill(m.inv_ls2, (1.0 / self.lengthscale ** 2).numpy())
+        _lib.fill(m.outputscale, self.outputscale.numpy())
+        _lib.fill(m.noise, self.noise.numpy())
+        m.x_train = x.data_ptr()
+        if self._fit_ws is None or self._fit_ws[0].size(1) != n or self._fit_ws[0].device != dev:
+            self._fit_ws = (torch.empty((n_s, n, n), dtype=torch.float64, device=dev),
+                            torch.empty((n_s, n, n), dtype=torch.float64, device=dev))
+        work, linv = self._fit_ws
+        alpha = torch.empty((n_s, n), dtype=torch.float64, device=dev)
+        logdet = torch.empty((n_s,), dtype=torch.float64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.sx_gp_fit(ctypes.byref(m), _lib.ptr(y), _lib.ptr(work), _lib.ptr(linv), _lib.ptr(alpha),
+                                 _lib.ptr(logdet), _lib.ptr(status), _lib.stream_ptr(dev)), 'sx_gp_fit')
+        return m, linv, alpha, logdet, status
 
     def _update_model(self, x_train: Tensor, y_train: Tensor) -> None:
         _lib.require_gpu(x_train, 'train_x')
@@ -105,22 +121,10 @@ class GpCemSSM(CemSSM):
         _lib.check(lib.sx_gp_pack_sizes(n_s, n_u, n, ctypes.byref(a_n), ctypes.byref(t_n)), 'sx_gp_pack_sizes')
         a_pack = torch.empty(a_n.value, dtype=torch.float64, device=dev)
         stage_tab = torch.empty(t_n.value, dtype=torch.int32, device=dev)
-        m = _lib.SxGpModel()
-        m.n_s, m.n_u, m.n_train = n_s, n_u, n
-        _lib.fill(m.inv_ls2, (1.0 / self.lengthscale ** 2).numpy())
-        _lib.fill(m.outputscale, self.outputscale.numpy())
-        _lib.fill(m.noise, self.noise.numpy())
-        m.x_train, m.a_pack, m.stage_tab = x.data_ptr(), a_pack.data_ptr(), stage_tab.data_ptr()
         # factorise on the device (sx_gp_fit), then lay the operands out for the matrix cores (sx_gp_pack)
-        work = torch.empty((n_s, n, n), dtype=torch.float64, device=dev)
-        linv = torch.empty((n_s, n, n), dtype=torch.float64, device=dev)
-        alpha = torch.empty((n_s, n), dtype=torch.float64, device=dev)
-        logdet = torch.empty((n_s,), dtype=torch.float64, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
-        stream = _lib.stream_ptr(dev)
-        _lib.check(lib.sx_gp_fit(ctypes.byref(m), _lib.ptr(y), _lib.ptr(work), _lib.ptr(linv), _lib.ptr(alpha),
-                                 _lib.ptr(logdet), _lib.ptr(status), stream), 'sx_gp_fit')
-        _lib.check(lib.sx_gp_pack(ctypes.byref(m), _lib.ptr(linv), _lib.ptr(alpha), stream), 'sx_gp_pack')
+        m, linv, alpha, logdet, status = self._fit(x, y)
+        m.a_pack, m.stage_tab = a_pack.data_ptr(), stage_tab.data_ptr()
+        _lib.check(lib.sx_gp_pack(ctypes.byref(m), _lib.ptr(linv), _lib.ptr(alpha), _lib.stream_ptr(dev)), 'sx_gp_pack')
         if int(status.item()) & _lib.SX_STATUS_NOT_PD:
             raise RuntimeError('the kernel matrix K + noise I is not positive definite for the current hyper-parameters')
         self._model = m
@@ -128,6 +132,21 @@ class GpCemSSM(CemSSM):
         self._alpha = alpha
         # 1/2 log det(I + K_d / noise_d) = sum log diag L_d - N/2 log noise_d
         self._info_gain = (logdet.cpu() - 0.5 * n * torch.log(self.noise)).numpy()
+
+    def mll_and_grad(self, x_train: Tensor, y_train: Tensor):
+        """Exact marginal log likelihood per output [n_s] and its gradient [n_s x (D + 2)] w.r.t.
+        (lengthscale, outputscale, noise), at the current hyper-parameters (host tensors)."""
+        x, y = x_train.detach().contiguous(), y_train.detach().contiguous()
+        m, linv, alpha, logdet, status = self._fit(x, y)
+        d_in = self.num_states + self.num_actions
+        mll = torch.empty((self.num_states,), dtype=torch.float64, device=x.device)
+        grad = torch.empty((self.num_states, d_in + 2), dtype=torch.float64, device=x.device)
+        _lib.check(_lib.lib().sx_gp_mll_grad(ctypes.byref(m), _lib.ptr(y), _lib.ptr(linv), _lib.ptr(alpha), _lib.ptr(logdet),
+                                             _lib.ptr(mll), _lib.ptr(grad), _lib.stream_ptr(x.device)), 'sx_gp_mll_grad')
+        host = torch.cat((mll, grad.reshape(-1), status.double())).cpu()
+        if int(host[-1]) & _lib.SX_STATUS_NOT_PD:
+            raise RuntimeError('the kernel matrix K + noise I is not positive definite for the current hyper-parameters')
+        return host[:self.num_states], host[self.num_states:-1].reshape(self.num_states, d_in + 2)
 
     def information_gain(self):
         """[n_s] information gain of the training inputs, per output (zeros without data)."""
@@ -150,28 +169,28 @@ class GpCemSSM(CemSSM):
         return self._model
 
     def _train_model(self, x_train: Tensor, y_train: Tensor) -> None:
-        """Adam (lr 0.01) on the exact marginal log likelihood, as the reference does (gp_ssm_cem.py:103-129)."""
+        """Adam (lr 0.01) on the exact marginal log likelihood, the reference's recipe (gp_ssm_cem.py:103-129): the
+        loss is -sum_d mll_d / N (gpytorch's ExactMarginalLogLikelihood divides by the number of data points).
+        Value and gradient come from the device (sx_gp_fit + sx_gp_mll_grad); the few-parameter Adam step and the
+        softplus chain rule stay on the host."""
         if self._training_iterations <= 0:
             return
-        dev = x_train.device
-        x, y = x_train.detach(), y_train.detach().t()                       # y [n_s x N]
-        n = x.size(0)
-        raw = [t.clone().to(dev).requires_grad_(True) for t in
-               (self._raw_lengthscale, self._raw_outputscale, self._raw_noise)]
+        n = x_train.size(0)
+        d_in = self.num_states + self.num_actions
+        raw = [self._raw_lengthscale.clone().requires_grad_(True), self._raw_outputscale.clone().requires_grad_(True),
+               self._raw_noise.clone().requires_grad_(True)]
         opt = torch.optim.Adam(raw, lr=0.01)
         losses = []
         for _ in range(self._training_iterations):
-            opt.zero_grad()
-            k = self._kernel_matrices(x, F.softplus(raw[0]), F.softplus(raw[1]), F.softplus(raw[2]) + self._noise_floor)
-            chol = torch.linalg.cholesky(k)
-            alpha = torch.cholesky_solve(y.unsqueeze(2), chol).squeeze(2)
-            mll = -0.5 * (y * alpha).sum(1) - torch.log(torch.diagonal(chol, dim1=1, dim2=2)).sum(1) \
-                - 0.5 * n * math.log(2 * math.pi)
-            loss = -(mll / n).sum()
-            loss.backward()
-            losses.append(loss.item())
+            self._raw_lengthscale, self._raw_outputscale, self._raw_noise = (t.detach() for t in raw)
+            mll, grad = self.mll_and_grad(x_train, y_train)
+            losses.append(float(-(mll / n).sum()))
+            # d loss / d raw = -(1/N) d mll / d theta * sigmoid(raw)   (theta = softplus(raw) [+ floor])
+            raw[0].grad = -(grad[:, :d_in] / n) * torch.sigmoid(raw[0].detach())
+            raw[1].grad = -(grad[:, d_in] / n) * torch.sigmoid(raw[1].detach())
+            raw[2].grad = -(grad[:, d_in + 1] / n) * torch.sigmoid(raw[2].detach())
             opt.step()
-        self._raw_lengthscale, self._raw_outputscale, self._raw_noise = (t.detach().cpu() for t in raw)
+        self._raw_lengthscale, self._raw_outputscale, self._raw_noise = (t.detach().clone() for t in raw)
         self._last_training_losses = losses
         self._update_model(x_train, y_train)
 

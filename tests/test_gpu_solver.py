@@ -348,3 +348,36 @@ def test_numpy_state_space_model_adapter():
     assert m2.shape == (1, 4) and np.array_equal(m2, m[:1])
     with pytest.raises(NotImplementedError):
         model.predict(z[:, :4], z[:, 4:], full_cov=True)
+
+
+def test_mll_and_gradient_vs_autograd():
+    """sx_gp_fit + sx_gp_mll_grad against torch autograd (CPU, float64) on the textbook formula."""
+    import math
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+    rng = np.random.default_rng(17)
+    n, n_s, n_u = 70, 2, 1
+    X = rng.uniform(-1, 1, size=(n, 3))
+    Y = np.stack([np.sin(2 * X[:, 0]) + X[:, 2], X[:, 1] ** 2], 1) + 0.05 * rng.normal(size=(n, 2))
+    ls = rng.uniform(0.5, 1.5, size=(2, 3))
+    s = np.array([0.8, 0.3])
+    nz = np.array([0.02, 0.05])
+    ssm = GpCemSSM(Conf(), n_s, n_u)
+    ssm.set_hyperparameters(ls, s, nz)
+    mll, grad = ssm.mll_and_grad(T(X), T(Y))
+    tl = torch.tensor(ls, requires_grad=True)
+    ts = torch.tensor(s, requires_grad=True)
+    tn = torch.tensor(nz, requires_grad=True)
+    tx, ty = torch.tensor(X), torch.tensor(Y)
+    vals = []
+    for d in range(2):
+        xs = tx / tl[d]
+        sq = ((xs[:, None, :] - xs[None, :, :]) ** 2).sum(2)
+        K = ts[d] * torch.exp(-0.5 * sq) + tn[d] * torch.eye(n, dtype=torch.float64)
+        L = torch.linalg.cholesky(K)
+        a = torch.cholesky_solve(ty[:, d:d + 1], L)[:, 0]
+        vals.append(-0.5 * (ty[:, d] * a).sum() - torch.log(torch.diagonal(L)).sum() - 0.5 * n * math.log(2 * math.pi))
+    torch.stack(vals).sum().backward()
+    np.testing.assert_allclose(mll.numpy(), torch.stack(vals).detach().numpy(), rtol=1e-10)
+    np.testing.assert_allclose(grad[:, :3].numpy(), tl.grad.numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(grad[:, 3].numpy(), ts.grad.numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(grad[:, 4].numpy(), tn.grad.numpy(), rtol=1e-8, atol=1e-10)

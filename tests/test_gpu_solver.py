@@ -381,3 +381,42 @@ def test_mll_and_gradient_vs_autograd():
     np.testing.assert_allclose(grad[:, :3].numpy(), tl.grad.numpy(), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(grad[:, 3].numpy(), ts.grad.numpy(), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(grad[:, 4].numpy(), tn.grad.numpy(), rtol=1e-8, atol=1e-10)
+
+
+def test_gp_ssm_shape_contracts_and_edge_cases():
+    """Mirrors the reference's shape tests for CemSSMs (test_ssm_cem.py:23-42,116-164, test_gp_ssm_cem.py:12-40)."""
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+    n_s, n_u = 2, 1
+    ssm = GpCemSSM(Conf(), n_s, n_u)
+    assert ssm.x_train is None and ssm.y_train is None and ssm.parametric is False
+    x = torch.rand((11, 3), dtype=torch.float64, device=DEV)
+    y = torch.rand((11, 2), dtype=torch.float64, device=DEV)
+    ssm.update_model(x, y, replace_old=True)
+    assert torch.equal(ssm.x_train, x) and torch.equal(ssm.y_train, y)
+    ssm.update_model(x[:4], y[:4], replace_old=False)
+    assert ssm.x_train.shape == (15, 3) and ssm.y_train.shape == (15, 2)
+    for n in (1, 3, 17):
+        states = torch.rand((n, n_s), dtype=torch.float64, device=DEV)
+        actions = torch.rand((n, n_u), dtype=torch.float64, device=DEV)
+        m, v, j = ssm.predict_with_jacobians(states, actions)
+        assert m.shape == (n, n_s) and v.shape == (n, n_s) and j.shape == (n, n_s, n_s + n_u)
+        m, v = ssm.predict_without_jacobians(states, actions)
+        assert m.shape == (n, n_s) and v.shape == (n, n_s)
+        mr, vr = ssm.predict_raw(torch.cat((states, actions), dim=1))
+        assert mr.shape == (n_s, n) and vr.shape == (n_s, n)
+        assert not m.requires_grad and (v > 0).all()
+    # empty batch
+    m, v, j = ssm.predict_with_jacobians(torch.empty((0, n_s), dtype=torch.float64, device=DEV),
+                                         torch.empty((0, n_u), dtype=torch.float64, device=DEV))
+    assert m.shape == (0, n_s) and j.shape == (0, n_s, 3)
+    # shape errors are ValueErrors, as with the reference's assert_shape
+    with pytest.raises(ValueError):
+        ssm.predict_with_jacobians(torch.rand((3, 3), dtype=torch.float64, device=DEV),
+                                   torch.rand((3, 1), dtype=torch.float64, device=DEV))
+    with pytest.raises(ValueError):
+        ssm.update_model(x, y[:, :1])
+    assert isinstance(ssm.collect_metrics(), dict)
+    with pytest.raises(NotImplementedError):
+        class LinConf(Conf):
+            exact_gp_kernel = 'linear'
+        GpCemSSM(LinConf(), 2, 1)

@@ -1277,8 +1277,9 @@ int64_t sx_gp_predict_workspace_bytes(const sx_gp_model* model, int P) {
 
 int sx_gp_predict(const sx_gp_model* model, const double* z, int P, double* mean, double* var, double* jac,
                   void* workspace, int64_t workspace_bytes, void* stream) {
-    if (!model || !z || !mean || !var || P < 0) return SX_ERR_ARG;
-    if (P == 0) return SX_OK;
+    if (!model || P < 0) return SX_ERR_ARG;
+    if (P == 0) return SX_OK;   // an empty batch is not an error (its pointers may be NULL)
+    if (!z || !mean || !var) return SX_ERR_ARG;
 #define CALL(NS, NU) \
     sx::launch_predict<NS, NU>(model, z, P, mean, var, jac, (double*)workspace, workspace_bytes, (hipStream_t)stream)
     SX_DISPATCH(model->n_s, model->n_u, CALL);

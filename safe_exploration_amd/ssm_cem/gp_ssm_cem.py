@@ -204,6 +204,8 @@ class GpCemSSM(CemSSM):
         mean = torch.empty((n, self.num_states), dtype=torch.float64, device=z.device)
         var = torch.empty_like(mean)
         jac = torch.empty((n, self.num_states, d_in), dtype=torch.float64, device=z.device) if jacobians else None
+        if n == 0:
+            return mean, var, jac
         if self._model is None:
             # no data: the prior (zero mean, s + noise variance, flat mean)
             mean.zero_()

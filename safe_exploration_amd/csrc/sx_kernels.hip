@@ -79,12 +79,13 @@ struct FitArgs {
     double* alpha;     // [n_s x N]
     double* logdet;    // [n_s]  sum log diag L
     int* status;
-    int n, D, n_s;
+    int n, D, n_s, panel_cols;
 };
 
 __global__ __launch_bounds__(kFitThreads) void gp_fit_kernel(FitArgs fa) {
     __shared__ double vec[kFitMaxN];
     __shared__ double red[kFitThreads];
+    extern __shared__ __attribute__((aligned(16))) double panel[];   // [n x panel_cols]
     const int d = blockIdx.x, tid = threadIdx.x, n = fa.n, D = fa.D;
     double* A = fa.lmat + (size_t)d * n * n;
     double* W = fa.linv + (size_t)d * n * n;
@@ -101,24 +102,50 @@ __global__ __launch_bounds__(kFitThreads) void gp_fit_kernel(FitArgs fa) {
         }
     }
     __syncthreads();
-    // 2. right-looking Cholesky
+    // 2. blocked right-looking Cholesky: a panel of nb columns is factored in LDS (its barriers wait on LDS only),
+    //    then the trailing matrix gets ONE rank-nb update in HBM per panel instead of one rank-1 update per column
     const int ty = tid >> 6, tx = tid & 63;
     bool bad = false;
-    for (int j = 0; j < n; ++j) {
-        const double ajj = A[(size_t)j * n + j];
-        const double piv = sqrt(ajj);
-        if (!(ajj > 0.0)) bad = true;
-        for (int i = j + 1 + tid; i < n; i += kFitThreads) {
-            const double v = A[(size_t)i * n + j] / piv;
-            A[(size_t)i * n + j] = v;
-            vec[i] = v;
+    const int nb_max = fa.panel_cols;
+    for (int j0 = 0; j0 < n; j0 += nb_max) {
+        const int nb = (n - j0 < nb_max) ? n - j0 : nb_max;
+        const int rows = n - j0;
+        // panel[r][c] = A[j0 + r][j0 + c], r >= c
+        for (int idx = tid; idx < rows * nb; idx += kFitThreads) {
+            const int r = idx / nb, c = idx - r * nb;
+            panel[idx] = (c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
         }
         __syncthreads();
-        if (tid == 0) A[(size_t)j * n + j] = piv;
-        for (int i = j + 1 + ty; i < n; i += kFitThreads / 64) {
-            const double li = vec[i];
+        for (int jj = 0; jj < nb; ++jj) {
+            const double ajj = panel[jj * nb + jj];
+            if (!(ajj > 0.0)) bad = true;
+            const double piv = sqrt(ajj);
+            __syncthreads();   // everyone has read the pivot before it is overwritten
+            for (int r = jj + tid; r < rows; r += kFitThreads) panel[r * nb + jj] = (r == jj) ? piv : panel[r * nb + jj] / piv;
+            __syncthreads();
+            // update the rest of the panel: columns jj+1 .. nb-1, rows >= column
+            const int ncols = nb - jj - 1;
+            for (int idx = tid; idx < (rows - jj - 1) * ncols; idx += kFitThreads) {
+                const int r = jj + 1 + idx / ncols, c = jj + 1 + idx % ncols;
+                if (c <= r) panel[r * nb + c] -= panel[r * nb + jj] * panel[c * nb + jj];
+            }
+            __syncthreads();
+        }
+        // write the factored panel back
+        for (int idx = tid; idx < rows * nb; idx += kFitThreads) {
+            const int r = idx / nb, c = idx - r * nb;
+            if (c <= r) A[(size_t)(j0 + r) * n + j0 + c] = panel[idx];
+        }
+        // trailing update: A[i][k] -= sum_c P[i][c] P[k][c]  for j0 + nb <= k <= i
+        for (int i = j0 + nb + ty; i < n; i += kFitThreads / 64) {
             double* row = A + (size_t)i * n;
-            for (int c = j + 1 + tx; c <= i; c += 64) row[c] -= li * vec[c];
+            const double* pi = panel + (size_t)(i - j0) * nb;
+            for (int c = j0 + nb + tx; c <= i; c += 64) {
+                const double* pc = panel + (size_t)(c - j0) * nb;
+                double s = 0.0;
+                for (int q = 0; q < nb; ++q) s += pi[q] * pc[q];
+                row[c] -= s;
+            }
         }
         __syncthreads();
     }
@@ -1215,7 +1242,19 @@ int sx_gp_fit(const sx_gp_model* model, const double* y_train, double* work, dou
     fa.n = model->n_train;
     fa.D = D;
     fa.n_s = model->n_s;
-    hipLaunchKernelGGL(sx::gp_fit_kernel, dim3(model->n_s), dim3(sx::kFitThreads), 0, (hipStream_t)stream, fa);
+    // panel width: as wide as the LDS left beside the static arrays allows (vec 32 KB + red 8 KB), at most 32
+    const size_t lds_budget = 112 * 1024;
+    int nb = (int)(lds_budget / (sizeof(double) * (size_t)fa.n));
+    nb = nb > 32 ? 32 : (nb < 1 ? 1 : nb);
+    fa.panel_cols = nb;
+    const size_t lds = sizeof(double) * (size_t)fa.n * nb;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(sx::gp_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return SX_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(sx::gp_fit_kernel, dim3(model->n_s), dim3(sx::kFitThreads), lds, (hipStream_t)stream, fa);
     return sx::check_launch();
 }
 

@@ -1,0 +1,258 @@
+// Warm path: sx_gp_fit / sx_gp_mll_grad / sx_gp_pack kernels (once per update_model or training iteration).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/sx_amd.h"
+#include "sx_gp.hpp"
+#include "sx_reach.hpp"
+
+namespace sx {
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_pack: W_d / alpha_d -> fragment order
+// ---------------------------------------------------------------------------------------------------------------
+template <int MAXNS, int MAXD>
+struct PackArgs {
+    double inv_ls2[MAXNS * MAXD];
+};
+
+// rows < N: W_d (lower triangular);  rows N .. N + D: alpha_d, alpha_d * X_j / l_dj^2;  above: zero
+__global__ void pack_a_kernel(const double* __restrict__ linv, const double* __restrict__ alpha,
+                              const double* __restrict__ x_train, PackArgs<SX_MAX_NS, SX_MAX_D> args, int n_s, int D, int n,
+                              int n_pad, double* __restrict__ a_pack) {
+    const int nrb = n_pad >> 4;
+    const int64_t wpo = w_pairs_per_output(nrb);
+    const int64_t total = (int64_t)n_s * wpo * 128;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i & 1);
+        const int lane = (int)((i >> 1) & 63);
+        int64_t pair = i >> 7;
+        const int d = (int)(pair / wpo);
+        pair -= (int64_t)d * wpo;
+        // row-block rb owns pairs [rb (rb + 1), (rb + 1)(rb + 2))
+        int rb = (int)((sqrt(4.0 * (double)pair + 1.0) - 1.0) * 0.5);
+        while ((int64_t)rb * (rb + 1) > pair) --rb;
+        while ((int64_t)(rb + 1) * (rb + 2) <= pair) ++rb;
+        const int q = (int)(pair - (int64_t)rb * (rb + 1));
+        const int row = rb * 16 + (lane & 15);
+        const int k = 8 * q + 4 * slot + (lane >> 4);
+        double v = 0.0;
+        if (row < n) {
+            if (k <= row) v = linv[((int64_t)d * n + row) * n + k];
+        } else if (row - n <= D && k < n) {
+            const int r = row - n;
+            const double al = alpha[(int64_t)d * n + k];
+            v = (r == 0) ? al : al * x_train[(int64_t)k * D + r - 1] * args.inv_ls2[d * D + r - 1];
+        }
+        a_pack[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_fit: K_d + noise_d I = L_d L_d^T, W_d = L_d^-1, alpha_d = W_d^T W_d y_d, log det L_d.   Warm path: once per
+// update_model.  One 1024-thread workgroup per output, everything in place in global memory (a workgroup lives on one
+// CU, so its own stores are visible to it after a barrier); the active column / row is staged in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFitThreads = 1024;
+constexpr int kFitMaxN = 4096;
+
+struct FitArgs {
+    double inv_ls2[SX_MAX_NS * SX_MAX_D];
+    double outputscale[SX_MAX_NS];
+    double noise[SX_MAX_NS];
+    const double* x;   // [N x D]
+    const double* y;   // [N x n_s]
+    double* lmat;      // [n_s x N x N]  K then L (lower triangle)
+    double* linv;      // [n_s x N x N]  W = L^-1
+    double* alpha;     // [n_s x N]
+    double* logdet;    // [n_s]  sum log diag L
+    int* status;
+    int n, D, n_s, panel_cols;
+};
+
+__global__ __launch_bounds__(kFitThreads) void gp_fit_kernel(FitArgs fa) {
+    __shared__ double vec[kFitMaxN];
+    __shared__ double red[kFitThreads];
+    extern __shared__ __attribute__((aligned(16))) double panel[];   // [n x panel_cols]
+    const int d = blockIdx.x, tid = threadIdx.x, n = fa.n, D = fa.D;
+    double* A = fa.lmat + (size_t)d * n * n;
+    double* W = fa.linv + (size_t)d * n * n;
+    // 1. kernel matrix (lower triangle)
+    for (int64_t idx = tid; idx < (int64_t)n * n; idx += kFitThreads) {
+        const int i = (int)(idx / n), j = (int)(idx - (int64_t)i * n);
+        if (j <= i) {
+            double q = 0.0;
+            for (int c = 0; c < D; ++c) {
+                const double df = fa.x[(size_t)i * D + c] - fa.x[(size_t)j * D + c];
+                q += df * df * fa.inv_ls2[d * D + c];
+            }
+            A[idx] = fa.outputscale[d] * exp(-0.5 * q) + (i == j ? fa.noise[d] : 0.0);
+        }
+    }
+    __syncthreads();
+    // 2. blocked right-looking Cholesky: a panel of nb columns is factored in LDS (its barriers wait on LDS only),
+    //    then the trailing matrix gets ONE rank-nb update in HBM per panel instead of one rank-1 update per column
+    const int ty = tid >> 6, tx = tid & 63;
+    bool bad = false;
+    const int nb_max = fa.panel_cols;
+    for (int j0 = 0; j0 < n; j0 += nb_max) {
+        const int nb = (n - j0 < nb_max) ? n - j0 : nb_max;
+        const int rows = n - j0;
+        // panel[r][c] = A[j0 + r][j0 + c], r >= c
+        for (int idx = tid; idx < rows * nb; idx += kFitThreads) {
+            const int r = idx / nb, c = idx - r * nb;
+            panel[idx] = (c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < nb; ++jj) {
+            const double ajj = panel[jj * nb + jj];
+            if (!(ajj > 0.0)) bad = true;
+            const double piv = sqrt(ajj);
+            __syncthreads();   // everyone has read the pivot before it is overwritten
+            for (int r = jj + tid; r < rows; r += kFitThreads) panel[r * nb + jj] = (r == jj) ? piv : panel[r * nb + jj] / piv;
+            __syncthreads();
+            // update the rest of the panel: columns jj+1 .. nb-1, rows >= column
+            const int ncols = nb - jj - 1;
+            for (int idx = tid; idx < (rows - jj - 1) * ncols; idx += kFitThreads) {
+                const int r = jj + 1 + idx / ncols, c = jj + 1 + idx % ncols;
+                if (c <= r) panel[r * nb + c] -= panel[r * nb + jj] * panel[c * nb + jj];
+            }
+            __syncthreads();
+        }
+        // write the factored panel back
+        for (int idx = tid; idx < rows * nb; idx += kFitThreads) {
+            const int r = idx / nb, c = idx - r * nb;
+            if (c <= r) A[(size_t)(j0 + r) * n + j0 + c] = panel[idx];
+        }
+        // trailing update: A[i][k] -= sum_c P[i][c] P[k][c]  for j0 + nb <= k <= i
+        for (int i = j0 + nb + ty; i < n; i += kFitThreads / 64) {
+            double* row = A + (size_t)i * n;
+            const double* pi = panel + (size_t)(i - j0) * nb;
+            for (int c = j0 + nb + tx; c <= i; c += 64) {
+                const double* pc = panel + (size_t)(c - j0) * nb;
+                double s = 0.0;
+                for (int q = 0; q < nb; ++q) s += pi[q] * pc[q];
+                row[c] -= s;
+            }
+        }
+        __syncthreads();
+    }
+    if (bad && tid == 0) atomicOr(fa.status, 8);
+    // 3. W = L^-1, row by row: W[i][c] = (delta_ic - sum_{k=c}^{i-1} L[i][k] W[k][c]) / L[i][i]
+    for (int i = 0; i < n; ++i) {
+        for (int c = tid; c <= i; c += kFitThreads) vec[c] = A[(size_t)i * n + c];
+        __syncthreads();
+        const double inv = 1.0 / vec[i];
+        for (int c = tid; c < n; c += kFitThreads) {
+            double w = 0.0;
+            if (c <= i) {
+                double s = (c == i) ? 1.0 : 0.0;
+                for (int kk = c; kk < i; ++kk) s -= vec[kk] * W[(size_t)kk * n + c];
+                w = s * inv;
+            }
+            W[(size_t)i * n + c] = w;
+        }
+        __syncthreads();
+    }
+    // 4. alpha = W^T (W y)
+    for (int i = tid; i < n; i += kFitThreads) {
+        double s = 0.0;
+        for (int c = 0; c <= i; ++c) s += W[(size_t)i * n + c] * fa.y[(size_t)c * fa.n_s + d];
+        vec[i] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += kFitThreads) {
+        double s = 0.0;
+        for (int i = c; i < n; ++i) s += W[(size_t)i * n + c] * vec[i];
+        fa.alpha[(size_t)d * n + c] = s;
+    }
+    // 5. sum log diag L
+    double ld = 0.0;
+    for (int i = tid; i < n; i += kFitThreads) ld += log(A[(size_t)i * n + i]);
+    red[tid] = ld;
+    __syncthreads();
+    for (int off = kFitThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) fa.logdet[d] = red[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_mll_grad: exact marginal log likelihood of output d and its gradient w.r.t. (lengthscale_d[0..D), outputscale_d,
+// noise_d), from the factorisation sx_gp_fit left behind:
+//   mll = -1/2 y.alpha - sum log diag L - N/2 log 2 pi,      d mll / d theta = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta),
+//   K^-1 = W^T W.   One workgroup per output; pair (i, j <= i) is handled by thread j (W rows are read coalesced).
+// ---------------------------------------------------------------------------------------------------------------
+struct MllArgs {
+    double inv_ls2[SX_MAX_NS * SX_MAX_D];
+    double outputscale[SX_MAX_NS];
+    double noise[SX_MAX_NS];
+    const double* x;
+    const double* y;
+    const double* linv;
+    const double* alpha;
+    const double* logdet;
+    double* mll;    // [n_s]
+    double* grad;   // [n_s x (D + 2)]
+    int n, D, n_s;
+};
+
+__global__ __launch_bounds__(kFitThreads) void gp_mll_grad_kernel(MllArgs ma) {
+    __shared__ double red[kFitThreads];
+    const int d = blockIdx.x, tid = threadIdx.x, n = ma.n, D = ma.D;
+    const double* W = ma.linv + (size_t)d * n * n;
+    const double* al = ma.alpha + (size_t)d * n;
+    double acc[SX_MAX_D + 2];
+#pragma unroll
+    for (int c = 0; c < SX_MAX_D + 2; ++c) acc[c] = 0.0;
+    double ya = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double ai = al[i];
+        for (int j = tid; j <= i; j += kFitThreads) {
+            double kinv = 0.0;
+            for (int r = i; r < n; ++r) kinv += W[(size_t)r * n + i] * W[(size_t)r * n + j];
+            const double g = ai * al[j] - kinv;
+            double q = 0.0;
+            double dq[SX_MAX_D];
+            for (int c = 0; c < D; ++c) {
+                const double df = ma.x[(size_t)i * D + c] - ma.x[(size_t)j * D + c];
+                dq[c] = df * df * ma.inv_ls2[d * D + c];   // (x_ic - x_jc)^2 / l_c^2
+                q += dq[c];
+            }
+            const double kij = ma.outputscale[d] * exp(-0.5 * q);
+            const double w = (i == j) ? 0.5 : 1.0;         // 1/2 tr(...) over the symmetric pair
+            for (int c = 0; c < D; ++c) acc[c] += w * g * kij * dq[c];          // * 1 / l_c applied below
+            acc[D] += w * g * kij;                                              // * 1 / s applied below
+            if (i == j) acc[D + 1] += 0.5 * g;
+        }
+        if (i % kFitThreads == tid) ya += ma.y[(size_t)i * ma.n_s + d] * ai;
+    }
+    for (int c = 0; c < D + 3; ++c) {
+        double v = (c < D + 2) ? acc[c] : ya;
+        red[tid] = v;
+        __syncthreads();
+        for (int off = kFitThreads / 2; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double tot = red[0];
+            if (c < D)
+                ma.grad[d * (D + 2) + c] = tot * sqrt(ma.inv_ls2[d * D + c]);   // dK/dl_c = K (x_i - x_j)^2 / l_c^3
+            else if (c == D)
+                ma.grad[d * (D + 2) + D] = tot / ma.outputscale[d];
+            else if (c == D + 1)
+                ma.grad[d * (D + 2) + D + 1] = tot;
+            else
+                ma.mll[d] = -0.5 * tot - ma.logdet[d] - 0.5 * n * 1.8378770664093453;   // log(2 pi)
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap) {
+    if ((int)threadIdx.x < nw) gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x);
+}
+
+}  // namespace sx

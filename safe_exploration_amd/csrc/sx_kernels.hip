@@ -1,4 +1,4 @@
-// libsxamd: kernels + C ABI (include/sx_amd.h).  gfx950 only.
+// libsxamd: launchers + C ABI (include/sx_amd.h) over the kernels in sx_*.hpp.  gfx950 only.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -9,263 +9,15 @@
 #include "sx_gp.hpp"
 #include "sx_reach.hpp"
 #include "sx_big.hpp"
+#include "sx_fit.hpp"
+#include "sx_rollout.hpp"
+#include "sx_rank.hpp"
 
 namespace sx {
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 
-#ifndef SX_ROLLOUT_THREADS
-#define SX_ROLLOUT_THREADS (64 * SX_WAVES)
-#endif
-constexpr int kRolloutThreads = SX_ROLLOUT_THREADS;  // waves of the CU that owns the 16-particle tile
 constexpr int kPredictThreads = 64 * SX_WAVES;
-
-// ---------------------------------------------------------------------------------------------------------------
-// sx_gp_pack: W_d / alpha_d -> fragment order
-// ---------------------------------------------------------------------------------------------------------------
-template <int MAXNS, int MAXD>
-struct PackArgs {
-    double inv_ls2[MAXNS * MAXD];
-};
-
-// rows < N: W_d (lower triangular);  rows N .. N + D: alpha_d, alpha_d * X_j / l_dj^2;  above: zero
-__global__ void pack_a_kernel(const double* __restrict__ linv, const double* __restrict__ alpha,
-                              const double* __restrict__ x_train, PackArgs<SX_MAX_NS, SX_MAX_D> args, int n_s, int D, int n,
-                              int n_pad, double* __restrict__ a_pack) {
-    const int nrb = n_pad >> 4;
-    const int64_t wpo = w_pairs_per_output(nrb);
-    const int64_t total = (int64_t)n_s * wpo * 128;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int slot = (int)(i & 1);
-        const int lane = (int)((i >> 1) & 63);
-        int64_t pair = i >> 7;
-        const int d = (int)(pair / wpo);
-        pair -= (int64_t)d * wpo;
-        // row-block rb owns pairs [rb (rb + 1), (rb + 1)(rb + 2))
-        int rb = (int)((sqrt(4.0 * (double)pair + 1.0) - 1.0) * 0.5);
-        while ((int64_t)rb * (rb + 1) > pair) --rb;
-        while ((int64_t)(rb + 1) * (rb + 2) <= pair) ++rb;
-        const int q = (int)(pair - (int64_t)rb * (rb + 1));
-        const int row = rb * 16 + (lane & 15);
-        const int k = 8 * q + 4 * slot + (lane >> 4);
-        double v = 0.0;
-        if (row < n) {
-            if (k <= row) v = linv[((int64_t)d * n + row) * n + k];
-        } else if (row - n <= D && k < n) {
-            const int r = row - n;
-            const double al = alpha[(int64_t)d * n + k];
-            v = (r == 0) ? al : al * x_train[(int64_t)k * D + r - 1] * args.inv_ls2[d * D + r - 1];
-        }
-        a_pack[i] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// sx_gp_fit: K_d + noise_d I = L_d L_d^T, W_d = L_d^-1, alpha_d = W_d^T W_d y_d, log det L_d.   Warm path: once per
-// update_model.  One 1024-thread workgroup per output, everything in place in global memory (a workgroup lives on one
-// CU, so its own stores are visible to it after a barrier); the active column / row is staged in LDS.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kFitThreads = 1024;
-constexpr int kFitMaxN = 4096;
-
-struct FitArgs {
-    double inv_ls2[SX_MAX_NS * SX_MAX_D];
-    double outputscale[SX_MAX_NS];
-    double noise[SX_MAX_NS];
-    const double* x;   // [N x D]
-    const double* y;   // [N x n_s]
-    double* lmat;      // [n_s x N x N]  K then L (lower triangle)
-    double* linv;      // [n_s x N x N]  W = L^-1
-    double* alpha;     // [n_s x N]
-    double* logdet;    // [n_s]  sum log diag L
-    int* status;
-    int n, D, n_s, panel_cols;
-};
-
-__global__ __launch_bounds__(kFitThreads) void gp_fit_kernel(FitArgs fa) {
-    __shared__ double vec[kFitMaxN];
-    __shared__ double red[kFitThreads];
-    extern __shared__ __attribute__((aligned(16))) double panel[];   // [n x panel_cols]
-    const int d = blockIdx.x, tid = threadIdx.x, n = fa.n, D = fa.D;
-    double* A = fa.lmat + (size_t)d * n * n;
-    double* W = fa.linv + (size_t)d * n * n;
-    // 1. kernel matrix (lower triangle)
-    for (int64_t idx = tid; idx < (int64_t)n * n; idx += kFitThreads) {
-        const int i = (int)(idx / n), j = (int)(idx - (int64_t)i * n);
-        if (j <= i) {
-            double q = 0.0;
-            for (int c = 0; c < D; ++c) {
-                const double df = fa.x[(size_t)i * D + c] - fa.x[(size_t)j * D + c];
-                q += df * df * fa.inv_ls2[d * D + c];
-            }
-            A[idx] = fa.outputscale[d] * exp(-0.5 * q) + (i == j ? fa.noise[d] : 0.0);
-        }
-    }
-    __syncthreads();
-    // 2. blocked right-looking Cholesky: a panel of nb columns is factored in LDS (its barriers wait on LDS only),
-    //    then the trailing matrix gets ONE rank-nb update in HBM per panel instead of one rank-1 update per column
-    const int ty = tid >> 6, tx = tid & 63;
-    bool bad = false;
-    const int nb_max = fa.panel_cols;
-    for (int j0 = 0; j0 < n; j0 += nb_max) {
-        const int nb = (n - j0 < nb_max) ? n - j0 : nb_max;
-        const int rows = n - j0;
-        // panel[r][c] = A[j0 + r][j0 + c], r >= c
-        for (int idx = tid; idx < rows * nb; idx += kFitThreads) {
-            const int r = idx / nb, c = idx - r * nb;
-            panel[idx] = (c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : 0.0;
-        }
-        __syncthreads();
-        for (int jj = 0; jj < nb; ++jj) {
-            const double ajj = panel[jj * nb + jj];
-            if (!(ajj > 0.0)) bad = true;
-            const double piv = sqrt(ajj);
-            __syncthreads();   // everyone has read the pivot before it is overwritten
-            for (int r = jj + tid; r < rows; r += kFitThreads) panel[r * nb + jj] = (r == jj) ? piv : panel[r * nb + jj] / piv;
-            __syncthreads();
-            // update the rest of the panel: columns jj+1 .. nb-1, rows >= column
-            const int ncols = nb - jj - 1;
-            for (int idx = tid; idx < (rows - jj - 1) * ncols; idx += kFitThreads) {
-                const int r = jj + 1 + idx / ncols, c = jj + 1 + idx % ncols;
-                if (c <= r) panel[r * nb + c] -= panel[r * nb + jj] * panel[c * nb + jj];
-            }
-            __syncthreads();
-        }
-        // write the factored panel back
-        for (int idx = tid; idx < rows * nb; idx += kFitThreads) {
-            const int r = idx / nb, c = idx - r * nb;
-            if (c <= r) A[(size_t)(j0 + r) * n + j0 + c] = panel[idx];
-        }
-        // trailing update: A[i][k] -= sum_c P[i][c] P[k][c]  for j0 + nb <= k <= i
-        for (int i = j0 + nb + ty; i < n; i += kFitThreads / 64) {
-            double* row = A + (size_t)i * n;
-            const double* pi = panel + (size_t)(i - j0) * nb;
-            for (int c = j0 + nb + tx; c <= i; c += 64) {
-                const double* pc = panel + (size_t)(c - j0) * nb;
-                double s = 0.0;
-                for (int q = 0; q < nb; ++q) s += pi[q] * pc[q];
-                row[c] -= s;
-            }
-        }
-        __syncthreads();
-    }
-    if (bad && tid == 0) atomicOr(fa.status, 8);
-    // 3. W = L^-1, row by row: W[i][c] = (delta_ic - sum_{k=c}^{i-1} L[i][k] W[k][c]) / L[i][i]
-    for (int i = 0; i < n; ++i) {
-        for (int c = tid; c <= i; c += kFitThreads) vec[c] = A[(size_t)i * n + c];
-        __syncthreads();
-        const double inv = 1.0 / vec[i];
-        for (int c = tid; c < n; c += kFitThreads) {
-            double w = 0.0;
-            if (c <= i) {
-                double s = (c == i) ? 1.0 : 0.0;
-                for (int kk = c; kk < i; ++kk) s -= vec[kk] * W[(size_t)kk * n + c];
-                w = s * inv;
-            }
-            W[(size_t)i * n + c] = w;
-        }
-        __syncthreads();
-    }
-    // 4. alpha = W^T (W y)
-    for (int i = tid; i < n; i += kFitThreads) {
-        double s = 0.0;
-        for (int c = 0; c <= i; ++c) s += W[(size_t)i * n + c] * fa.y[(size_t)c * fa.n_s + d];
-        vec[i] = s;
-    }
-    __syncthreads();
-    for (int c = tid; c < n; c += kFitThreads) {
-        double s = 0.0;
-        for (int i = c; i < n; ++i) s += W[(size_t)i * n + c] * vec[i];
-        fa.alpha[(size_t)d * n + c] = s;
-    }
-    // 5. sum log diag L
-    double ld = 0.0;
-    for (int i = tid; i < n; i += kFitThreads) ld += log(A[(size_t)i * n + i]);
-    red[tid] = ld;
-    __syncthreads();
-    for (int off = kFitThreads / 2; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
-    }
-    if (tid == 0) fa.logdet[d] = red[0];
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// sx_gp_mll_grad: exact marginal log likelihood of output d and its gradient w.r.t. (lengthscale_d[0..D), outputscale_d,
-// noise_d), from the factorisation sx_gp_fit left behind:
-//   mll = -1/2 y.alpha - sum log diag L - N/2 log 2 pi,      d mll / d theta = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta),
-//   K^-1 = W^T W.   One workgroup per output; pair (i, j <= i) is handled by thread j (W rows are read coalesced).
-// ---------------------------------------------------------------------------------------------------------------
-struct MllArgs {
-    double inv_ls2[SX_MAX_NS * SX_MAX_D];
-    double outputscale[SX_MAX_NS];
-    double noise[SX_MAX_NS];
-    const double* x;
-    const double* y;
-    const double* linv;
-    const double* alpha;
-    const double* logdet;
-    double* mll;    // [n_s]
-    double* grad;   // [n_s x (D + 2)]
-    int n, D, n_s;
-};
-
-__global__ __launch_bounds__(kFitThreads) void gp_mll_grad_kernel(MllArgs ma) {
-    __shared__ double red[kFitThreads];
-    const int d = blockIdx.x, tid = threadIdx.x, n = ma.n, D = ma.D;
-    const double* W = ma.linv + (size_t)d * n * n;
-    const double* al = ma.alpha + (size_t)d * n;
-    double acc[SX_MAX_D + 2];
-#pragma unroll
-    for (int c = 0; c < SX_MAX_D + 2; ++c) acc[c] = 0.0;
-    double ya = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const double ai = al[i];
-        for (int j = tid; j <= i; j += kFitThreads) {
-            double kinv = 0.0;
-            for (int r = i; r < n; ++r) kinv += W[(size_t)r * n + i] * W[(size_t)r * n + j];
-            const double g = ai * al[j] - kinv;
-            double q = 0.0;
-            double dq[SX_MAX_D];
-            for (int c = 0; c < D; ++c) {
-                const double df = ma.x[(size_t)i * D + c] - ma.x[(size_t)j * D + c];
-                dq[c] = df * df * ma.inv_ls2[d * D + c];   // (x_ic - x_jc)^2 / l_c^2
-                q += dq[c];
-            }
-            const double kij = ma.outputscale[d] * exp(-0.5 * q);
-            const double w = (i == j) ? 0.5 : 1.0;         // 1/2 tr(...) over the symmetric pair
-            for (int c = 0; c < D; ++c) acc[c] += w * g * kij * dq[c];          // * 1 / l_c applied below
-            acc[D] += w * g * kij;                                              // * 1 / s applied below
-            if (i == j) acc[D + 1] += 0.5 * g;
-        }
-        if (i % kFitThreads == tid) ya += ma.y[(size_t)i * ma.n_s + d] * ai;
-    }
-    for (int c = 0; c < D + 3; ++c) {
-        double v = (c < D + 2) ? acc[c] : ya;
-        red[tid] = v;
-        __syncthreads();
-        for (int off = kFitThreads / 2; off > 0; off >>= 1) {
-            if (tid < off) red[tid] += red[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const double tot = red[0];
-            if (c < D)
-                ma.grad[d * (D + 2) + c] = tot * sqrt(ma.inv_ls2[d * D + c]);   // dK/dl_c = K (x_i - x_j)^2 / l_c^3
-            else if (c == D)
-                ma.grad[d * (D + 2) + D] = tot / ma.outputscale[d];
-            else if (c == D + 1)
-                ma.grad[d * (D + 2) + D + 1] = tot;
-            else
-                ma.mll[d] = -0.5 * tot - ma.logdet[d] - 0.5 * n * 1.8378770664093453;   // log(2 pi)
-        }
-        __syncthreads();
-    }
-}
-
-__global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap) {
-    if ((int)threadIdx.x < nw) gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // sx_gp_predict: one 16-point tile per workgroup
@@ -388,538 +140,6 @@ __global__ void polytope_kernel(PolyArgs<NS> pa, int P, double c_safety, const d
     const bool viol = polytope_violated<SX_MAX_M, NS>(pa.h_mat, pa.h_vec, pa.m, c_safety, p, Q, d);
     for (int r = 0; r < pa.m; ++r) d_out[g * pa.m + r] = d[r];
     if (inside) inside[g] = viol ? 0 : 1;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// sx_cem_rollout: the fused H-step particle rollout.  One workgroup = 16 particles of one problem for all H steps.
-// ---------------------------------------------------------------------------------------------------------------
-#ifdef SX_STAMPS
-// Diagnostic build only (tools/phase_stamps.py): per-workgroup cycle sums of the three phases of a step.
-__device__ unsigned long long* g_stamp_buf = nullptr;
-__device__ __forceinline__ unsigned long long stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#endif
-
-struct RolloutPtrs {
-    const double* x0;
-    const double* q0;
-    const double* mean;
-    const double* std;
-    const double* noise;
-    double* actions;
-    double* traj;
-    double* sigma;
-    double* obj_cost;
-    double* con_cost;
-    int* status;
-    int E, P, H;
-};
-
-template <int NS, int NU>
-__global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS, NS + NU> gc,
-                                                                      const int4* __restrict__ stage_tab,
-                                                                      ReachConst<NS, NU> rc,
-                                                                      CostConst<SX_MAX_M, NS, NU> cc, RolloutPtrs rp) {
-    constexpr int D = NS + NU;
-    constexpr int S = NS + NS * NS;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    GpTileLds<NS, D> lds;
-    const int nw = blockDim.x >> 6;
-    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw);  // [16][H][NU]
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int H = rp.H;
-    const int tiles_per_problem = (rp.P + SX_TILE - 1) / SX_TILE;
-    const int e = blockIdx.x / tiles_per_problem;
-    const int c0 = (blockIdx.x - e * tiles_per_problem) * SX_TILE;  // first particle of the tile within problem e
-
-    gp_load_xs(gc, lds);
-    // sample (or load) this tile's action sequences: a = mean + std * eps
-    for (int i = tid; i < SX_TILE * H * NU; i += blockDim.x) {
-        const int c = i / (H * NU);
-        const int r = i - c * (H * NU);
-        double a = 0.0;
-        if (c0 + c < rp.P) {
-            const int64_t gi = ((int64_t)e * rp.P + c0 + c) * (H * NU) + r;
-            if (rp.noise) {
-                a = rp.mean[(int64_t)e * H * NU + r] + rp.std[(int64_t)e * H * NU + r] * rp.noise[gi];
-                rp.actions[gi] = a;
-            } else {
-                a = rp.actions[gi];
-            }
-        }
-        acts[i] = a;
-    }
-    // per-particle state lives in the registers of thread c (tid < 16) for the whole rollout
-    const bool owner = tid < SX_TILE;
-    const bool valid = owner && (c0 + tid < rp.P);
-    double p[NS], Q[NS][NS];
-    bool have_q = rp.q0 != nullptr;
-    double obj = 0.0, con = 0.0;
-    int st = 0;
-    if (owner) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            p[i] = rp.x0[(int64_t)e * NS + i];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) Q[i][j] = have_q ? rp.q0[((int64_t)e * NS + i) * NS + j] : 0.0;
-        }
-    }
-    __syncthreads();
-    if (owner) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = p[i];
-#pragma unroll
-        for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + 0) * NU + cidx];
-    }
-    __syncthreads();
-
-    // Step t:   Kstar(t)  |sync|  MFMA(t)  |sync|  quick(t): p_{t+1} = mean + a p + b u  ->  zs  |sync|
-    // The rest of step t (variance, Jacobian, ellipsoid algebra, costs: ~4.5k cycles on 16 lanes) does not feed
-    // Kstar(t+1), so wave 0 runs it DURING Kstar(t+1) while waves 1..7 compute the kernel rows.
-    double pn[NS];  // p_{t+1} from quick(t), kept for finish(t)
-    auto quick = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            double s = lds.mj[i * 256 + tid];  // posterior mean of output i
-#pragma unroll
-            for (int j = 0; j < NS; ++j) s += rc.a[i * NS + j] * p[j];
-#pragma unroll
-            for (int cidx = 0; cidx < NU; ++cidx) s += rc.b[i * NU + cidx] * acts[(tid * H + t) * NU + cidx];
-            pn[i] = s;
-        }
-        if (t + 1 < H) {
-#pragma unroll
-            for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = pn[i];
-#pragma unroll
-            for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
-        }
-    };
-    auto finish = [&](int t) {
-        double z[D], u[NU], mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) z[j] = p[j];
-#pragma unroll
-        for (int cidx = 0; cidx < NU; ++cidx) {
-            u[cidx] = acts[(tid * H + t) * NU + cidx];
-            z[NS + cidx] = u[cidx];
-        }
-        int st_step = 0;
-        if (have_q) {
-            gp_collect<NS, D, true>(gc, lds, nw, tid, z, mean, var, jac);
-            reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st_step);
-        } else {
-            gp_collect<NS, D, false>(gc, lds, nw, tid, z, mean, var, jac);
-            reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st_step);
-        }
-        have_q = true;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) p1[i] = pn[i];  // exactly the centre the next GP query used
-        if (valid) st |= st_step;
-        // costs (safempc_cem.py:102-132,304-312; action constraint: test_safempc_cem.py:59-71)
-        obj += objective_cost<SX_MAX_M, NS, NU>(cc, p1, var);
-        bool uviol = false;
-#pragma unroll
-        for (int cidx = 0; cidx < NU; ++cidx) uviol = uviol || (u[cidx] < cc.u_min[cidx]) || (u[cidx] > cc.u_max[cidx]);
-        if (uviol) con += SX_ACTION_VIOLATION_COST;
-        if (cc.con_mode == SX_CON_ALL_STATES || t == H - 1) {
-            if (polytope_violated<SX_MAX_M, NS>(cc.h_mat, cc.h_vec, cc.m, 1.0, p1, Q1, nullptr))
-                con += SX_STATE_VIOLATION_COST;
-        }
-        const int64_t g = (int64_t)e * rp.P + c0 + tid;
-        if (valid && rp.traj) {
-            double* tr = rp.traj + (g * H + t) * S;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                tr[i] = p1[i];
-#pragma unroll
-                for (int j = 0; j < NS; ++j) tr[NS + i * NS + j] = Q1[i][j];
-            }
-        }
-        if (valid && rp.sigma) {
-#pragma unroll
-            for (int i = 0; i < NS; ++i) rp.sigma[(g * H + t) * NS + i] = var[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            p[i] = p1[i];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) Q[i][j] = Q1[i][j];
-        }
-    };
-
-#ifdef SX_STAMPS
-    unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0, c_e = 0, c_eb = 0;
-#endif
-    for (int t = 0; t < H; ++t) {
-#ifdef SX_STAMPS
-        const unsigned long long t0 = stamp();
-#endif
-        if (t == 0) {
-            gp_kstar_phase(gc, lds);
-        } else if (wave == 0) {
-            if (owner) finish(t - 1);
-        } else {
-            gp_kstar_phase(gc, lds, 64);
-        }
-#ifdef SX_STAMPS
-        const unsigned long long t1 = stamp();
-#endif
-        __syncthreads();
-#ifdef SX_STAMPS
-        const unsigned long long t2 = stamp();
-#endif
-        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane);
-#ifdef SX_STAMPS
-        const unsigned long long t3 = stamp();
-#endif
-        __syncthreads();
-#ifdef SX_STAMPS
-        const unsigned long long t4 = stamp();
-#endif
-        if (owner) quick(t);
-#ifdef SX_STAMPS
-        const unsigned long long t5 = stamp();
-#endif
-        __syncthreads();
-#ifdef SX_STAMPS
-        const unsigned long long t6 = stamp();
-        c_k += t1 - t0; c_kb += t2 - t1; c_m += t3 - t2; c_mb += t4 - t3; c_e += t5 - t4; c_eb += t6 - t5;
-#endif
-    }
-    if (owner) finish(H - 1);
-#ifdef SX_STAMPS
-    if (g_stamp_buf && lane == 0) {
-        unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * nw + wave) * 8;
-        o[0] = c_k; o[1] = c_kb; o[2] = c_m; o[3] = c_mb; o[4] = c_e; o[5] = c_eb;
-    }
-#endif
-    if (valid) {
-        const int64_t g = (int64_t)e * rp.P + c0 + tid;
-        rp.obj_cost[g] = obj;
-        rp.con_cost[g] = con;
-        if (st) atomicOr(rp.status, st);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// sx_cem_rank_refit: one workgroup (16 waves) per problem.
-//   1. every thread keeps its candidates' 128-bit keys (con, obj) in registers: element i lives in slot i / 1024 of
-//      thread i % 1024, so (slot, thread) order is index order;
-//   2. MSB-first radix select of the k-th key, 8 bits per pass: wave-aggregated LDS histogram (one atomic per wave when
-//      all lanes agree -- the common case in the high bytes), bin scan by one wave, early exit as soon as the bin
-//      holding the k-th key is wholly selected;
-//   3. ballot compaction in index order (ties broken by the lower index); the best survivor is moved to the front,
-//      the others stay where the compaction put them (nothing downstream needs them sorted);
-//   4. refit: mean / unbiased std over the elites, rows spread over the whole workgroup.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kRankThreads = 1024;
-constexpr int kRankWaves = kRankThreads / 64;
-constexpr int kRankMaxK = 2048;
-constexpr int kRankSlots = 16;  // candidates per thread held in registers: P <= 16384
-
-__device__ __forceinline__ unsigned long long sortable_key(double x) {
-    if (x != x) return ~0ull;  // NaN last
-    unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
-}
-
-struct RankArgs {
-    int P, k, row_len;
-    const double* con;
-    const double* obj;
-    long long cost_stride;
-    const double* actions;
-    long long act_stride;
-    int* elite_idx;
-    double* elite_rows;
-    double* mean;
-    double* std;
-    double* best;
-    int* best_ok;
-};
-
-template <int SLOTS>
-__global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned long long sel_hi[kRankMaxK], sel_lo[kRankMaxK];
-    __shared__ int sel_idx[kRankMaxK];
-    __shared__ double red[kRankThreads];
-    __shared__ double col_mean[256];
-    __shared__ int wave_cnt[kRankWaves][2];
-    __shared__ unsigned long long red_u64[kRankWaves], red_lo[kRankWaves];
-    __shared__ int sh_digit, sh_need, sh_done;
-
-    const int e = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int P = ra.P, k = ra.k;
-    const double* con = ra.con + (long long)e * P * ra.cost_stride;
-    const double* obj = ra.obj + (long long)e * P * ra.cost_stride;
-    const double* act = ra.actions + (long long)e * P * ra.act_stride;
-
-    unsigned long long kh[SLOTS], kl[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int i = s * kRankThreads + tid;
-        kh[s] = ~0ull;
-        kl[s] = ~0ull;
-        if (i < P) {
-            kh[s] = sortable_key(con[(long long)i * ra.cost_stride]);
-            kl[s] = sortable_key(obj[(long long)i * ra.cost_stride]);
-        }
-    }
-
-#ifdef SX_STAMPS
-    const unsigned long long ts0 = stamp();
-#endif
-    // ---- radix select ----
-    unsigned long long ph = 0, pl = 0;   // prefix of the k-th key found so far (uniform)
-    unsigned long long mh = 0, ml = 0;   // mask of the prefix bits
-    int need = k;                        // rank of the k-th key among the candidates matching the prefix
-    bool done = false;
-    int first_pass = 0;
-    {
-        // The constraint word takes few distinct values (0 for every feasible particle, then 3 a + 10 b), so its
-        // k-th smallest value is found by walking up the distinct values: one (min, multiplicity) reduction per value,
-        // at most 8 of them, instead of eight radix passes.  (Beyond 8 the general passes below take over.)
-        unsigned long long floor_key = 0;  // only keys >= floor_key are still in play
-        int acc = 0;                       // candidates below floor_key
-        for (int it = 0; it < 8; ++it) {
-            unsigned long long mn = ~0ull;
-            int cnt = 0;
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const bool in_play = (s * kRankThreads + tid < P) && kh[s] >= floor_key;
-                if (in_play) {
-                    if (kh[s] < mn) { mn = kh[s]; cnt = 1; } else if (kh[s] == mn) { ++cnt; }
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long om = __shfl_xor(mn, off);
-                const int oc = __shfl_xor(cnt, off);
-                if (om < mn) { mn = om; cnt = oc; } else if (om == mn) { cnt += oc; }
-            }
-            if (lane == 0) { red_u64[wave] = mn; wave_cnt[wave][0] = cnt; }
-            __syncthreads();
-            mn = red_u64[0];
-            cnt = wave_cnt[0][0];
-#pragma unroll
-            for (int w = 1; w < kRankWaves; ++w) {
-                const unsigned long long om = red_u64[w];
-                const int oc = wave_cnt[w][0];
-                if (om < mn) { mn = om; cnt = oc; } else if (om == mn) { cnt += oc; }
-            }
-            __syncthreads();
-            if (acc + cnt >= k) {   // the k-th key has this constraint word
-                ph = mn;
-                mh = ~0ull;
-                need = k - acc;
-                first_pass = 8;
-                break;
-            }
-            acc += cnt;
-            floor_key = mn + 1;
-        }
-    }
-    for (int pass = first_pass; pass < 16 && !done; ++pass) {
-        const int shift = 56 - 8 * (pass & 7);
-        const bool in_hi = pass < 8;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int i = s * kRankThreads + tid;
-            const bool match = (i < P) && ((kh[s] & mh) == ph) && ((kl[s] & ml) == pl);
-            const unsigned int digit = match ? (unsigned int)(((in_hi ? kh[s] : kl[s]) >> shift) & 255ull) : 0xffffffffu;
-            const unsigned int first = __builtin_amdgcn_readfirstlane(digit);
-            if (__all(digit == first)) {
-                if (first != 0xffffffffu && lane == 0) atomicAdd(&hist[first], 64u);
-            } else if (match) {
-                atomicAdd(&hist[digit], 1u);
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // lane l owns bins 4l .. 4l+3
-            const unsigned int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
-            const int mine = (int)(c0 + c1 + c2 + c3);
-            int incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off);
-                if (lane >= off) incl += v;
-            }
-            const int before = incl - mine;
-            if (need > before && need <= incl) {
-                int rem = need - before;
-                int dsel = 4 * lane;
-                unsigned int cnt = c0;
-                if (rem > (int)c0) { rem -= c0; dsel++; cnt = c1;
-                    if (rem > (int)c1) { rem -= c1; dsel++; cnt = c2;
-                        if (rem > (int)c2) { rem -= c2; dsel++; cnt = c3; } } }
-                sh_digit = dsel;
-                sh_need = rem;
-                sh_done = (rem == (int)cnt) ? 1 : 0;  // the whole bin is selected: no need to look at lower digits
-            }
-        }
-        __syncthreads();
-        const unsigned long long dg = (unsigned long long)sh_digit << shift, mk = 255ull << shift;
-        if (in_hi) { ph |= dg; mh |= mk; } else { pl |= dg; ml |= mk; }
-        need = sh_need;
-        done = sh_done != 0;
-    }
-#ifdef SX_STAMPS
-    const unsigned long long ts1 = stamp();
-#endif
-    // Candidates whose masked key is below the prefix are selected; of those equal to it, the first `need` in index
-    // order (all of them after an early exit).
-    const int n_less_total = k - need;
-    int base_less = 0, base_tie = 0;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        if (s * kRankThreads >= P) break;
-        const int i = s * kRankThreads + tid;
-        const unsigned long long a_h = kh[s] & mh, a_l = kl[s] & ml;
-        const bool valid = i < P;
-        const bool less = valid && (a_h < ph || (a_h == ph && a_l < pl));
-        const bool tie = valid && a_h == ph && a_l == pl;
-        const unsigned long long bl = __ballot(less), bt = __ballot(tie);
-        if (lane == 0) {
-            wave_cnt[wave][0] = __popcll(bl);
-            wave_cnt[wave][1] = __popcll(bt);
-        }
-        __syncthreads();
-        int off_less = base_less, off_tie = base_tie, tot_less = 0, tot_tie = 0;
-#pragma unroll
-        for (int w = 0; w < kRankWaves; ++w) {
-            const int cl = wave_cnt[w][0], ct = wave_cnt[w][1];
-            if (w < wave) { off_less += cl; off_tie += ct; }
-            tot_less += cl;
-            tot_tie += ct;
-        }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (less) {
-            const int slot = off_less + __popcll(bl & below);
-            sel_hi[slot] = kh[s]; sel_lo[slot] = kl[s]; sel_idx[slot] = i;
-        } else if (tie) {
-            const int r = off_tie + __popcll(bt & below);
-            if (r < need) {
-                const int slot = n_less_total + r;
-                sel_hi[slot] = kh[s]; sel_lo[slot] = kl[s]; sel_idx[slot] = i;
-            }
-        }
-        base_less += tot_less;
-        base_tie += tot_tie;
-        __syncthreads();
-    }
-#ifdef SX_STAMPS
-    const unsigned long long ts2 = stamp();
-#endif
-    // ---- the elites stay where the compaction put them; only the best one is moved to the front ----
-    {
-        unsigned long long bh = ~0ull, bl = ~0ull;
-        int bi = 0x7fffffff, bslot = 0;
-        for (int i = tid; i < k; i += kRankThreads) {
-            const unsigned long long h = sel_hi[i], l = sel_lo[i];
-            const int ix = sel_idx[i];
-            if (h < bh || (h == bh && (l < bl || (l == bl && ix < bi)))) { bh = h; bl = l; bi = ix; bslot = i; }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long oh = __shfl_xor(bh, off), ol = __shfl_xor(bl, off);
-            const int oi = __shfl_xor(bi, off), os = __shfl_xor(bslot, off);
-            if (oh < bh || (oh == bh && (ol < bl || (ol == bl && oi < bi)))) { bh = oh; bl = ol; bi = oi; bslot = os; }
-        }
-        if (lane == 0) { red_u64[wave] = bh; red_lo[wave] = bl; wave_cnt[wave][0] = bi; wave_cnt[wave][1] = bslot; }
-        __syncthreads();
-        if (tid == 0) {
-            int best_w = 0;
-            for (int w = 1; w < kRankWaves; ++w) {
-                const unsigned long long oh = red_u64[w], ol = red_lo[w], ch = red_u64[best_w], cl = red_lo[best_w];
-                if (oh < ch || (oh == ch && (ol < cl || (ol == cl && wave_cnt[w][0] < wave_cnt[best_w][0])))) best_w = w;
-            }
-            const int s = wave_cnt[best_w][1];
-            const unsigned long long th = sel_hi[0], tl = sel_lo[0];
-            const int ti = sel_idx[0];
-            sel_hi[0] = sel_hi[s]; sel_lo[0] = sel_lo[s]; sel_idx[0] = sel_idx[s];
-            sel_hi[s] = th; sel_lo[s] = tl; sel_idx[s] = ti;
-        }
-        __syncthreads();
-    }
-#ifdef SX_STAMPS
-    const unsigned long long ts3 = stamp();
-#endif
-    // ---- outputs ----
-    const int L = ra.row_len;
-    if (ra.elite_idx)
-        for (int i = tid; i < k; i += kRankThreads) ra.elite_idx[(long long)e * k + i] = sel_idx[i];
-    if (ra.elite_rows) {
-        const int W = 2 + L;
-        for (int i = tid; i < k * W; i += kRankThreads) {
-            const int r = i / W, c = i - r * W;
-            const int src = sel_idx[r];
-            double v;
-            if (c == 0)
-                v = con[(long long)src * ra.cost_stride];
-            else if (c == 1)
-                v = obj[(long long)src * ra.cost_stride];
-            else
-                v = act[(long long)src * ra.act_stride + (c - 2)];
-            ra.elite_rows[((long long)e * k + r) * W + c] = v;
-        }
-    }
-    if (ra.best)
-        for (int c = tid; c < L; c += kRankThreads) ra.best[(long long)e * L + c] = act[(long long)sel_idx[0] * ra.act_stride + c];
-    if (ra.best_ok && tid == 0) ra.best_ok[e] = (con[(long long)sel_idx[0] * ra.cost_stride] == 0.0) ? 1 : 0;
-    if (ra.mean) {
-        // columns in chunks of up to 256; thread t sums rows t / Lc, t / Lc + R, ... of column t % Lc
-        for (int c0 = 0; c0 < L; c0 += 256) {
-            const int Lc = (L - c0) < 256 ? (L - c0) : 256;
-            const int R = kRankThreads / Lc;  // row groups
-            const int c = tid % Lc, r0 = tid / Lc;
-            const bool active = r0 < R;
-            double s = 0.0;
-            if (active)
-                for (int r = r0; r < k; r += R) s += act[(long long)sel_idx[r] * ra.act_stride + c0 + c];
-            red[tid] = s;
-            __syncthreads();
-            if (tid < Lc) {
-                double t = 0.0;
-                for (int g = 0; g < R; ++g) t += red[g * Lc + tid];
-                col_mean[tid] = t / k;
-            }
-            __syncthreads();
-            const double mu = col_mean[c];
-            double ss = 0.0;
-            if (active)
-                for (int r = r0; r < k; r += R) {
-                    const double dv = act[(long long)sel_idx[r] * ra.act_stride + c0 + c] - mu;
-                    ss += dv * dv;
-                }
-            red[tid] = ss;
-            __syncthreads();
-            if (tid < Lc) {
-                double t = 0.0;
-                for (int g = 0; g < R; ++g) t += red[g * Lc + tid];
-                ra.mean[(long long)e * L + c0 + tid] = col_mean[tid];
-                if (ra.std) ra.std[(long long)e * L + c0 + tid] = (k > 1) ? sqrt(t / (k - 1)) : 0.0;
-            }
-            __syncthreads();
-        }
-    }
-#ifdef SX_STAMPS
-    const unsigned long long ts4 = stamp();
-    if (g_stamp_buf && tid == 0 && e == 0) {
-        g_stamp_buf[0] = ts1 - ts0; g_stamp_buf[1] = ts2 - ts1; g_stamp_buf[2] = ts3 - ts2; g_stamp_buf[3] = ts4 - ts3;
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,233 @@
+// The fused CEM particle rollout kernel (sx_cem_rollout, training sets that fit the LDS budget).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/sx_amd.h"
+#include "sx_gp.hpp"
+#include "sx_reach.hpp"
+
+namespace sx {
+
+#ifndef SX_ROLLOUT_THREADS
+#define SX_ROLLOUT_THREADS (64 * SX_WAVES)
+#endif
+constexpr int kRolloutThreads = SX_ROLLOUT_THREADS;  // waves of the CU that owns the 16-particle tile
+
+// ---------------------------------------------------------------------------------------------------------------
+// sx_cem_rollout: the fused H-step particle rollout.  One workgroup = 16 particles of one problem for all H steps.
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef SX_STAMPS
+// Diagnostic build only (tools/phase_stamps.py): per-workgroup cycle sums of the three phases of a step.
+__device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
+struct RolloutPtrs {
+    const double* x0;
+    const double* q0;
+    const double* mean;
+    const double* std;
+    const double* noise;
+    double* actions;
+    double* traj;
+    double* sigma;
+    double* obj_cost;
+    double* con_cost;
+    int* status;
+    int E, P, H;
+};
+
+template <int NS, int NU>
+__global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS, NS + NU> gc,
+                                                                      const int4* __restrict__ stage_tab,
+                                                                      ReachConst<NS, NU> rc,
+                                                                      CostConst<SX_MAX_M, NS, NU> cc, RolloutPtrs rp) {
+    constexpr int D = NS + NU;
+    constexpr int S = NS + NS * NS;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    GpTileLds<NS, D> lds;
+    const int nw = blockDim.x >> 6;
+    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw);  // [16][H][NU]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int H = rp.H;
+    const int tiles_per_problem = (rp.P + SX_TILE - 1) / SX_TILE;
+    const int e = blockIdx.x / tiles_per_problem;
+    const int c0 = (blockIdx.x - e * tiles_per_problem) * SX_TILE;  // first particle of the tile within problem e
+
+    gp_load_xs(gc, lds);
+    // sample (or load) this tile's action sequences: a = mean + std * eps
+    for (int i = tid; i < SX_TILE * H * NU; i += blockDim.x) {
+        const int c = i / (H * NU);
+        const int r = i - c * (H * NU);
+        double a = 0.0;
+        if (c0 + c < rp.P) {
+            const int64_t gi = ((int64_t)e * rp.P + c0 + c) * (H * NU) + r;
+            if (rp.noise) {
+                a = rp.mean[(int64_t)e * H * NU + r] + rp.std[(int64_t)e * H * NU + r] * rp.noise[gi];
+                rp.actions[gi] = a;
+            } else {
+                a = rp.actions[gi];
+            }
+        }
+        acts[i] = a;
+    }
+    // per-particle state lives in the registers of thread c (tid < 16) for the whole rollout
+    const bool owner = tid < SX_TILE;
+    const bool valid = owner && (c0 + tid < rp.P);
+    double p[NS], Q[NS][NS];
+    bool have_q = rp.q0 != nullptr;
+    double obj = 0.0, con = 0.0;
+    int st = 0;
+    if (owner) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            p[i] = rp.x0[(int64_t)e * NS + i];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) Q[i][j] = have_q ? rp.q0[((int64_t)e * NS + i) * NS + j] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (owner) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = p[i];
+#pragma unroll
+        for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + 0) * NU + cidx];
+    }
+    __syncthreads();
+
+    // Step t:   Kstar(t)  |sync|  MFMA(t)  |sync|  quick(t): p_{t+1} = mean + a p + b u  ->  zs  |sync|
+    // The rest of step t (variance, Jacobian, ellipsoid algebra, costs: ~4.5k cycles on 16 lanes) does not feed
+    // Kstar(t+1), so wave 0 runs it DURING Kstar(t+1) while waves 1..7 compute the kernel rows.
+    double pn[NS];  // p_{t+1} from quick(t), kept for finish(t)
+    auto quick = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            double s = lds.mj[i * 256 + tid];  // posterior mean of output i
+#pragma unroll
+            for (int j = 0; j < NS; ++j) s += rc.a[i * NS + j] * p[j];
+#pragma unroll
+            for (int cidx = 0; cidx < NU; ++cidx) s += rc.b[i * NU + cidx] * acts[(tid * H + t) * NU + cidx];
+            pn[i] = s;
+        }
+        if (t + 1 < H) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = pn[i];
+#pragma unroll
+            for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
+        }
+    };
+    auto finish = [&](int t) {
+        double z[D], u[NU], mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) z[j] = p[j];
+#pragma unroll
+        for (int cidx = 0; cidx < NU; ++cidx) {
+            u[cidx] = acts[(tid * H + t) * NU + cidx];
+            z[NS + cidx] = u[cidx];
+        }
+        int st_step = 0;
+        if (have_q) {
+            gp_collect<NS, D, true>(gc, lds, nw, tid, z, mean, var, jac);
+            reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st_step);
+        } else {
+            gp_collect<NS, D, false>(gc, lds, nw, tid, z, mean, var, jac);
+            reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st_step);
+        }
+        have_q = true;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) p1[i] = pn[i];  // exactly the centre the next GP query used
+        if (valid) st |= st_step;
+        // costs (safempc_cem.py:102-132,304-312; action constraint: test_safempc_cem.py:59-71)
+        obj += objective_cost<SX_MAX_M, NS, NU>(cc, p1, var);
+        bool uviol = false;
+#pragma unroll
+        for (int cidx = 0; cidx < NU; ++cidx) uviol = uviol || (u[cidx] < cc.u_min[cidx]) || (u[cidx] > cc.u_max[cidx]);
+        if (uviol) con += SX_ACTION_VIOLATION_COST;
+        if (cc.con_mode == SX_CON_ALL_STATES || t == H - 1) {
+            if (polytope_violated<SX_MAX_M, NS>(cc.h_mat, cc.h_vec, cc.m, 1.0, p1, Q1, nullptr))
+                con += SX_STATE_VIOLATION_COST;
+        }
+        const int64_t g = (int64_t)e * rp.P + c0 + tid;
+        if (valid && rp.traj) {
+            double* tr = rp.traj + (g * H + t) * S;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                tr[i] = p1[i];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) tr[NS + i * NS + j] = Q1[i][j];
+            }
+        }
+        if (valid && rp.sigma) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) rp.sigma[(g * H + t) * NS + i] = var[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            p[i] = p1[i];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) Q[i][j] = Q1[i][j];
+        }
+    };
+
+#ifdef SX_STAMPS
+    unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0, c_e = 0, c_eb = 0;
+#endif
+    for (int t = 0; t < H; ++t) {
+#ifdef SX_STAMPS
+        const unsigned long long t0 = stamp();
+#endif
+        if (t == 0) {
+            gp_kstar_phase(gc, lds);
+        } else if (wave == 0) {
+            if (owner) finish(t - 1);
+        } else {
+            gp_kstar_phase(gc, lds, 64);
+        }
+#ifdef SX_STAMPS
+        const unsigned long long t1 = stamp();
+#endif
+        __syncthreads();
+#ifdef SX_STAMPS
+        const unsigned long long t2 = stamp();
+#endif
+        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane);
+#ifdef SX_STAMPS
+        const unsigned long long t3 = stamp();
+#endif
+        __syncthreads();
+#ifdef SX_STAMPS
+        const unsigned long long t4 = stamp();
+#endif
+        if (owner) quick(t);
+#ifdef SX_STAMPS
+        const unsigned long long t5 = stamp();
+#endif
+        __syncthreads();
+#ifdef SX_STAMPS
+        const unsigned long long t6 = stamp();
+        c_k += t1 - t0; c_kb += t2 - t1; c_m += t3 - t2; c_mb += t4 - t3; c_e += t5 - t4; c_eb += t6 - t5;
+#endif
+    }
+    if (owner) finish(H - 1);
+#ifdef SX_STAMPS
+    if (g_stamp_buf && lane == 0) {
+        unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * nw + wave) * 8;
+        o[0] = c_k; o[1] = c_kb; o[2] = c_m; o[3] = c_mb; o[4] = c_e; o[5] = c_eb;
+    }
+#endif
+    if (valid) {
+        const int64_t g = (int64_t)e * rp.P + c0 + tid;
+        rp.obj_cost[g] = obj;
+        rp.con_cost[g] = con;
+        if (st) atomicOr(rp.status, st);
+    }
+}
+
+}  // namespace sx

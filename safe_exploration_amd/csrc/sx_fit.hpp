@@ -146,9 +146,18 @@ __global__ __launch_bounds__(kFitThreads) void gp_fit_kernel(FitArgs fa) {
         for (int c = tid; c < n; c += kFitThreads) {
             double w = 0.0;
             if (c <= i) {
-                double s = (c == i) ? 1.0 : 0.0;
-                for (int kk = c; kk < i; ++kk) s -= vec[kk] * W[(size_t)kk * n + c];
-                w = s * inv;
+                // four independent partial sums: the loads of W (HBM/L2) overlap instead of queueing behind one
+                // dependent accumulate chain
+                double s0 = (c == i) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int kk = c;
+                for (; kk + 4 <= i; kk += 4) {
+                    s0 -= vec[kk] * W[(size_t)kk * n + c];
+                    s1 -= vec[kk + 1] * W[(size_t)(kk + 1) * n + c];
+                    s2 -= vec[kk + 2] * W[(size_t)(kk + 2) * n + c];
+                    s3 -= vec[kk + 3] * W[(size_t)(kk + 3) * n + c];
+                }
+                for (; kk < i; ++kk) s0 -= vec[kk] * W[(size_t)kk * n + c];
+                w = ((s0 + s1) + (s2 + s3)) * inv;
             }
             W[(size_t)i * n + c] = w;
         }
@@ -210,8 +219,16 @@ __global__ __launch_bounds__(kFitThreads) void gp_mll_grad_kernel(MllArgs ma) {
     for (int i = 0; i < n; ++i) {
         const double ai = al[i];
         for (int j = tid; j <= i; j += kFitThreads) {
-            double kinv = 0.0;
-            for (int r = i; r < n; ++r) kinv += W[(size_t)r * n + i] * W[(size_t)r * n + j];
+            double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0;   // independent partial sums: loads overlap
+            int r = i;
+            for (; r + 4 <= n; r += 4) {
+                k0 += W[(size_t)r * n + i] * W[(size_t)r * n + j];
+                k1 += W[(size_t)(r + 1) * n + i] * W[(size_t)(r + 1) * n + j];
+                k2 += W[(size_t)(r + 2) * n + i] * W[(size_t)(r + 2) * n + j];
+                k3 += W[(size_t)(r + 3) * n + i] * W[(size_t)(r + 3) * n + j];
+            }
+            for (; r < n; ++r) k0 += W[(size_t)r * n + i] * W[(size_t)r * n + j];
+            const double kinv = (k0 + k1) + (k2 + k3);
             const double g = ai * al[j] - kinv;
             double q = 0.0;
             double dq[SX_MAX_D];

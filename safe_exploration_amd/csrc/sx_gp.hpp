@@ -289,6 +289,17 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         st.w = desc.w;
         desc = stages[inext + 1];
     };
+    // the same, split so that step() can spread it: an f64 MFMA leaves its wave only ~4 free issue slots
+    // (tools/mfma_probe2.hip), so the ~13 non-MFMA instructions of a stage go 4 / 4 / 3 / 2 between the four MFMAs
+    auto decode_a = [&](MfmaStage& st) {
+        aoff = desc.x << 10;
+        st.z = desc.z;
+        st.w = desc.w;
+    };
+    auto decode_b = [&](int inext) {
+        bp = kbase + desc.y;
+        desc = stages[inext + 1];
+    };
     auto load_a = [&](int byte_off) -> v2d {
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(arsrc, lane16, aoff + byte_off, 0);
@@ -308,16 +319,19 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
     auto step = [&](const MfmaStage& cur, MfmaStage& nx, int inext) {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a0.x, cur.b0.x, acc, 0, 0, 0);
         SX_PIN();
-        decode(nx, inext);
+        decode_a(nx);
         nx.a0 = load_a(0);
-        nx.a1 = load_a(1024);
         SX_PIN();
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a0.y, cur.b0.y, acc, 0, 0, 0);
+        SX_PIN();
+        nx.a1 = load_a(1024);
+        decode_b(inext);
+        SX_PIN();
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.x, cur.b1.x, acc, 0, 0, 0);
         SX_PIN();
         nx.b0 = bp[0];
         nx.b1 = bp[64];
         SX_PIN();
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.x, cur.b1.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.y, cur.b1.y, acc, 0, 0, 0);
         SX_PIN();
         if (cur.w & kStageLast) {

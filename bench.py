@@ -42,34 +42,32 @@ def pmc_traffic(workload_key):
 
 
 
-def cpu_baseline(spec, horizon, particles, elites, budget_s=12.0, max_iters=8):
-    """The numpy oracle (a port of the reference's arithmetic) on the host cores: a bounded sample of the workload."""
+def cpu_baseline(spec, horizon, particles, elites, budget_s=12.0, max_iters=64):
+    """The oracle's C restatement (oracle/csrc, OpenMP over particles; a port of the reference's arithmetic) on the host
+    cores, on a bounded sample of the same workload: whole CEM iterations until `budget_s` seconds are spent."""
     import numpy as np
+    from oracle import c_oracle
     from oracle import cem as ocem
     from oracle.gp import ExactGP
     from safe_exploration_amd import problems
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
     gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
     prob = problems.oracle_problem(spec, ocem)
     rng = np.random.default_rng(1)
     mean, std = np.zeros((horizon, spec.n_u)), np.full((horizon, spec.n_u), 0.1)
     x0 = np.array([0.02, -0.03] + [0.0] * (spec.n_s - 2))[:spec.n_s]
+    c_oracle.rollout(prob, gp, x0, mean[None] + std[None] * rng.normal(size=(64, horizon, spec.n_u)), want_traj=False)
     done, t0 = 0, time.perf_counter()
-    with np.errstate(all='ignore'):
-        while done < max_iters and (time.perf_counter() - t0) < budget_s:
-            acts = mean[None] + std[None] * rng.normal(size=(particles, horizon, spec.n_u))
-            res = ocem.rollout(prob, gp, x0, acts)
-            idx = ocem.rank(res.con_cost, res.obj_cost, elites)
-            mean, std = ocem.refit(acts[idx])
-            done += 1
+    while done < max_iters and (time.perf_counter() - t0) < budget_s:
+        acts = mean[None] + std[None] * rng.normal(size=(particles, horizon, spec.n_u))
+        res = c_oracle.rollout(prob, gp, x0, acts, want_traj=False)
+        idx = ocem.rank(res.con_cost, res.obj_cost, elites)
+        mean, std = ocem.refit(acts[idx])
+        done += 1
     dt = time.perf_counter() - t0
-    return {'value': particles * horizon * done / dt, 'unit': 'particle-steps/s', 'cores': int(threads), 'kind': 'port',
-            'sample': f'{done} CEM iteration(s) of the same workload ({particles} particles x H={horizon}), numpy '
-                      f'float64 oracle, {dt:.1f} s'}
+    return {'value': particles * horizon * done / dt, 'unit': 'particle-steps/s', 'cores': c_oracle.max_threads(),
+            'kind': 'port',
+            'sample': f'{done} CEM iteration(s) of the same workload ({particles} particles x H={horizon}), C oracle '
+                      f'(oracle/csrc, OpenMP, float64), {dt:.1f} s'}
 
 
 def main():

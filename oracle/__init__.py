@@ -1,7 +1,9 @@
 """CPU oracle for the CEM safe-MPC hot path.  TEST INFRASTRUCTURE ONLY.
 
 This package is a numpy float64 restatement of the reference algorithm (oscarkey/safe-exploration) for the one
-path this repository accelerates.  It exists to CHECK the HIP path, never to serve it:
+path this repository accelerates, plus a plain-C restatement of the rollout (``oracle/csrc``, OpenMP over particles;
+``oracle.c_oracle``) that serves as a second check and as the CPU baseline of ``bench.py``.  It exists to CHECK the HIP
+path, never to serve it:
 
 * only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it;
 * nothing under ``safe_exploration_amd/`` imports it, and the product path raises if the HIP library is missing.

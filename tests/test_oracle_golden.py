@@ -161,3 +161,42 @@ def test_rank_and_refit():
     m, s = cem.refit(acts)
     np.testing.assert_allclose(m, acts.mean(0))
     np.testing.assert_allclose(s, acts.std(0, ddof=1))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_c_oracle_chained_rollout_vs_reference_golden(golden_dir, name):
+    """The C restatement (oracle/csrc) is pinned the same way as the numpy one: against the reference's outputs."""
+    from oracle import c_oracle
+    g = load(golden_dir, name)
+    n_s, n_u = g['p'].shape[1], g['k_ff'].shape[1]
+    a, b = lin(g)
+    if a is None:
+        a, b = np.eye(n_s), np.zeros((n_s, n_u))
+    prob = cem.Problem(n_s, n_u, a, b, g['k_fb'], g['l_mu'], g['l_sigma'], float(g['c_safety']),
+                       np.eye(n_s), np.ones((n_s, 1)), -np.ones(n_u), np.ones(n_u))
+    gp = gp_of(g)
+    for i in range(g['p'].shape[0]):   # every golden particle starts from its own point
+        res = c_oracle.rollout(prob, gp, g['p'][i], g['actions'][i:i + 1])
+        np.testing.assert_allclose(res.traj_p[0], g['chain_p'][i], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res.traj_q[0], g['chain_q'][i], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(res.sigma[0], g['chain_sigma'][i], rtol=1e-9, atol=1e-12)
+
+
+def test_c_oracle_matches_numpy_oracle_on_costs():
+    from oracle import c_oracle
+    from safe_exploration_amd import problems
+    for which, n, H in (('pendulum', 120, 7), ('cartpole', 90, 5)):
+        spec = getattr(problems, which)(n_train=n, seed=3, **({'obj_mode': 1} if which == 'pendulum' else {}))
+        gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+        prob = problems.oracle_problem(spec, cem)
+        rng = np.random.default_rng(5)
+        acts = rng.normal(0, 0.3, size=(60, H, spec.n_u))
+        x0 = rng.normal(0, 0.02, size=spec.n_s)
+        with np.errstate(all='ignore'):
+            ref = cem.rollout(prob, gp, x0, acts)
+        got = c_oracle.rollout(prob, gp, x0, acts)
+        np.testing.assert_allclose(got.traj_p, ref.traj_p, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(got.traj_q, ref.traj_q, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(got.obj_cost, ref.obj_cost, rtol=1e-9, atol=1e-12)
+        np.testing.assert_array_equal(got.con_cost, ref.con_cost)
+        assert got.status == ref.status == 0

@@ -420,3 +420,37 @@ def test_gp_ssm_shape_contracts_and_edge_cases():
         class LinConf(Conf):
             exact_gp_kernel = 'linear'
         GpCemSSM(LinConf(), 2, 1)
+
+
+def test_config3_and_config5_shapes():
+    """Full-size shapes of BASELINE configs 3 and 5 on one GPU's share, through size-independent properties.
+    Config 3: 65 536 particles x H=30 over 8 GPUs = 8192 particles per GPU.  Config 5: 64 episodes x 4096 particles
+    striped over 8 GPUs = 8 episodes per GPU in one launch."""
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.cem_mpc import FusedCemMpc, cem_rollout
+    spec = problems.pendulum(n_train=200, seed=0)
+    ssm, env = problems.build(spec, DEV)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(3)
+    # config 3 share: replicated action sequences must give bit-identical particles wherever they sit in the batch
+    P, H, R = 8192, 30, 64
+    base = 0.05 * torch.randn((R, H, 1), dtype=torch.float64, device=DEV, generator=gen)
+    acts = base.repeat(P // R, 1, 1).unsqueeze(0).contiguous()
+    x0 = T([[0.01, -0.01]])
+    r = cem_rollout(ssm, env, x0, H, actions=acts)
+    obj = r['obj_cost'][0].view(P // R, R)
+    con = r['con_cost'][0].view(P // R, R)
+    assert torch.equal(obj, obj[:1].expand_as(obj)) and torch.equal(con, con[:1].expand_as(con))
+    # (over 30 steps the ellipsoids of this problem outgrow float64 -- the reference would abort on the NaN too; the
+    # variance-based objective stays finite)
+    assert torch.isfinite(obj).all()
+    # config 5 share: 8 episodes x 4096 particles in one launch == the same episodes solved one at a time
+    E, P5, H5, k, iters = 8, 4096, 15, 409, 2
+    noise = torch.randn((iters, E, P5, H5, 1), dtype=torch.float64, device=DEV, generator=gen)
+    x0s = 0.02 * torch.randn((E, 2), dtype=torch.float64, device=DEV, generator=gen)
+    mpc = FusedCemMpc(ssm, env, H5, P5, k, iters, device=DEV, init_std=0.1)
+    best, ok, _, status = mpc.solve(x0s, noise=noise)
+    for e in (0, 5):
+        b1, ok1, _, _ = mpc.solve(x0s[e:e + 1].contiguous(), noise=noise[:, e:e + 1].contiguous())
+        assert torch.equal(b1[0], best[e]) and int(ok1[0]) == int(ok[e])
+    assert int(status.item()) == 0

@@ -91,7 +91,9 @@ typedef struct sx_env {
 /* Library / build identification: returns "sxamd <version> gfx950". */
 const char* sx_version(void);
 
+#ifndef SX_WAVES
 #define SX_WAVES 8               /* waves per workgroup in the GP kernels (the stage table is laid out for it) */
+#endif
 
 /* Sizes of sx_gp_model.a_pack (doubles) and sx_gp_model.stage_tab (int32). */
 int sx_gp_pack_sizes(int n_s, int n_u, int n_train, int64_t* a_doubles, int64_t* tab_ints);

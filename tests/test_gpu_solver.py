@@ -454,3 +454,47 @@ def test_config3_and_config5_shapes():
         b1, ok1, _, _ = mpc.solve(x0s[e:e + 1].contiguous(), noise=noise[:, e:e + 1].contiguous())
         assert torch.equal(b1[0], best[e]) and int(ok1[0]) == int(ok[e])
     assert int(status.item()) == 0
+
+
+@pytest.mark.parametrize('n_s,n_u', [(1, 1), (3, 1), (2, 2), (4, 2)])
+def test_other_state_action_dimensions(n_s, n_u):
+    """Every (n_s, n_u) pair the library instantiates goes through GP predict, one-step reachability and the fused
+    rollout against the oracle on a synthetic problem (random linear prior, LQR feedback, box polytope)."""
+    from safe_exploration_amd import _lib, problems
+    from safe_exploration_amd.cem_mpc import cem_rollout
+    from safe_exploration_amd.utils import dlqr
+    rng = np.random.default_rng(100 * n_s + n_u)
+    d_in = n_s + n_u
+    a = np.eye(n_s) + 0.05 * rng.normal(size=(n_s, n_s))
+    b = 0.3 * rng.normal(size=(n_s, n_u))
+    k_fb = -dlqr(a, b, np.eye(n_s), 5.0 * np.eye(n_u))[0]
+    X, Y = problems.synthetic_training_set(77, n_s, n_u, seed=n_s * 7 + n_u, scale=0.6)
+    ls = rng.uniform(0.6, 1.4, size=(n_s, d_in))
+    s, nz = rng.uniform(0.01, 0.03, size=n_s), rng.uniform(1e-5, 5e-5, size=n_s)
+    h_mat = np.vstack((np.eye(n_s), -np.eye(n_s)))
+    h_vec = np.full((2 * n_s, 1), 0.5 if n_s <= 2 else 1.2)
+    spec = problems.ProblemSpec('synthetic', n_s, n_u, X, Y, ls, s, nz, a, b, k_fb, rng.uniform(0.01, 0.05, size=n_s),
+                                rng.uniform(0.01, 0.05, size=n_s), 2.5, h_mat, h_vec, np.full(n_u, -0.4),
+                                np.full(n_u, 0.4), obj_mode=_lib.SX_OBJ_AFFINE_ABS, obj_w_abs=rng.uniform(0, 1, size=n_s),
+                                obj_target=rng.normal(0, 0.1, size=n_s), obj_w_lin=rng.normal(0, 0.2, size=n_s))
+    ssm, env = problems.build(spec, DEV)
+    gp = ExactGP(X, Y, ls, s, nz)
+    z = rng.uniform(-0.5, 0.5, size=(21, d_in))
+    m, v, j = ssm.predict_with_jacobians(T(z[:, :n_s]), T(z[:, n_s:]))
+    mo, vo, jo = gp.predict(z)
+    np.testing.assert_allclose(m.cpu().numpy(), mo, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(v.cpu().numpy(), vo, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(j.cpu().numpy(), jo, rtol=1e-9, atol=1e-11)
+    P, H = 53, 5
+    acts = rng.normal(0, 0.25, size=(P, H, n_u))
+    x0 = rng.normal(0, 0.02, size=n_s)
+    r = cem_rollout(ssm, env, T(x0[None]), H, actions=T(acts[None]), want_traj=True, want_sigma=True)
+    ref = ocem.rollout(problems.oracle_problem(spec, ocem), gp, x0, acts)
+    traj = r['traj'][0].cpu().numpy()
+    np.testing.assert_allclose(traj[:, :, :n_s], ref.traj_p, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(traj[:, :, n_s:].reshape(P, H, n_s, n_s), ref.traj_q, rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(r['sigma'][0].cpu().numpy(), ref.sigma, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(r['obj_cost'][0].cpu().numpy(), ref.obj_cost, rtol=1e-8, atol=1e-11)
+    np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
+    assert int(r['status'].item()) == ref.status == 0
+    assert (ref.con_cost > 0).any()

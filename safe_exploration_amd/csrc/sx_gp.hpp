@@ -18,6 +18,7 @@
 // W_d row-block rb (16 rows) has 2 (rb + 1) pairs (k <= 16 rb + 15), stored at pair offset rb (rb + 1).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/sx_amd.h"
 
 namespace sx {
@@ -89,14 +90,14 @@ struct GpConst {
 // LDS carve-up of one GP tile (all in doubles, 16-byte aligned pieces)
 template <int NS, int D>
 struct GpTileLds {
-    double* xs;     // [n_train x D]      training inputs, loaded once per kernel
+    double* xs;     // [n_pad x D]        training inputs (rows >= n_train zero), loaded once per kernel
     double* kfrag;  // [NS][n_pad x 16]   Kstar in fragment order
     double* mj;     // [NS][16 rows][16]  mean / Jacobian rows
     double* part;   // [NW][NS][16]       per-wave partial sums of squares
     double* zs;     // [16][D]            query points
     __device__ double* carve(double* base, int n_train, int n_pad, int nw) {
         xs = base;
-        kfrag = xs + ((n_train * D + 1) & ~1);
+        kfrag = xs + ((n_pad * D + 1) & ~1);
         mj = kfrag + (size_t)NS * n_pad * 16;
         part = mj + NS * 256;
         zs = part + (size_t)nw * NS * 16;
@@ -144,39 +145,46 @@ inline int gp_stage_cap(int ns, int n_pad, int nw) {
 inline int64_t gp_stage_tab_ints(int ns, int n_pad, int nw) { return 4 * (int64_t)nw * (1 + gp_stage_cap(ns, n_pad, nw)); }
 
 inline size_t gp_tile_lds_doubles(int ns, int d, int n_train, int n_pad, int nw) {
-    return (size_t)((n_train * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d;
+    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d;
 }
 
 template <int NS, int D>
 __device__ __forceinline__ void gp_load_xs(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds) {
-    for (int i = threadIdx.x; i < gc.n_train * D; i += blockDim.x) lds.xs[i] = gc.x_train[i];
+    for (int i = threadIdx.x; i < gc.n_pad * D; i += blockDim.x) lds.xs[i] = i < gc.n_train * D ? gc.x_train[i] : 0.0;
 }
 
-// Phase 1: Kstar_d[c][k] = s_d exp(-1/2 sum_j (z_cj - X_kj)^2 / l_dj^2) for the tile's 16 points, all k, all d.
-// Run by threads [first, blockDim.x), both multiples of 16: a thread keeps the same query point c = tid & 15 for every
+// Phase 1: Kstar_d[c][k] = s_d exp(-1/2 sum_j (z_cj - X_kj)^2 / l_dj^2) for the tile's 16 points, all k < n_pad, all d.
+// Run by threads [first, blockDim.x), both multiples of 64: a thread keeps the same query point c = tid & 15 for every
 // k it visits (threads below `first` are busy elsewhere -- the rollout's wave 0 finishes the previous step meanwhile).
+//
+// The phase is bound by VALU issue, on the pipe the f64 MFMAs use too (tools/overlap_probe.hip), so what counts is the
+// instruction count per value.  Columns k >= n_train of W and of the mean/Jacobian rows are zero (pack_a_kernel), so the
+// padding entries of Kstar only have to be finite: they are computed like any other from the zero rows gp_load_xs
+// appends to X -- no index clamp, no select.  A thread visits k0, k0 + kstep, k0 + 2 kstep, ...; kstep is a multiple
+// of 4, so two visits on, k & 7 is the same and both the X row and the fragment slot move by a constant.
 template <int NS, int D>
 __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int first = 0) {
     if ((int)threadIdx.x < first) return;
-    const int c = threadIdx.x & 15;
+    const int t = (int)threadIdx.x - first;
+    const int c = t & 15;
     double z[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) z[j] = lds.zs[c * D + j];
     const int kstep = ((int)blockDim.x - first) >> 4;
-    const size_t dstride = (size_t)gc.n_pad * 16;
-    // two training points per trip: 2 NS independent exp chains in flight per thread
-    for (int k0 = ((int)threadIdx.x - first) >> 4; k0 < gc.n_pad; k0 += 2 * kstep) {
-        double arg[2 * NS], val[2 * NS];
-        int fi[2];
+    const int dstride = gc.n_pad * 16;
+    const int k0 = t >> 4;
+
+    // M = 1 or 2 training points of this thread at once: M NS independent exp chains in flight
+    auto eval = [&](auto mtag, const double* x0, const double* x1, double* f0, double* f1) {
+        constexpr int M = decltype(mtag)::value;
+        double arg[M * NS], val[M * NS];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = k0 + h * kstep;
-            fi[h] = frag_index(c, k);
-            const int kk = k < gc.n_train ? k : 0;  // clamp: the value is discarded below
+        for (int h = 0; h < M; ++h) {
+            const double* xr = h ? x1 : x0;
             double sq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const double df = z[j] - lds.xs[kk * D + j];
+                const double df = z[j] - xr[j];
                 sq[j] = df * df;
             }
 #pragma unroll
@@ -187,16 +195,34 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
                 arg[h * NS + d] = a;
             }
         }
-        exp_f64_n<2 * NS>(arg, val);
+        exp_f64_n<M * NS>(arg, val);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = k0 + h * kstep;
-            if (k < gc.n_pad) {
+        for (int h = 0; h < M; ++h) {
+            double* f = h ? f1 : f0;
 #pragma unroll
-                for (int d = 0; d < NS; ++d) lds.kfrag[d * dstride + fi[h]] = (k < gc.n_train) ? val[h * NS + d] : 0.0;
-            }
+            for (int d = 0; d < NS; ++d) f[d * dstride] = val[h * NS + d];
         }
+    };
+
+    const double* x0 = lds.xs + k0 * D;
+    const double* x1 = x0 + kstep * D;
+    double* f0 = lds.kfrag + frag_index(c, k0);
+    double* f1 = lds.kfrag + frag_index(c, k0 + kstep);
+    const int xadv = 2 * kstep * D, fadv = kstep * 32;
+    // trips in which every thread has two points below n_pad: no conditions at all
+    const int nfull = gc.n_pad / (2 * kstep);
+    for (int trip = 0; trip < nfull; ++trip) {
+        eval(std::integral_constant<int, 2>{}, x0, x1, f0, f1);
+        x0 += xadv;
+        x1 += xadv;
+        f0 += fadv;
+        f1 += fadv;
     }
+    const int k = nfull * 2 * kstep + k0;
+    if (k + kstep < gc.n_pad)
+        eval(std::integral_constant<int, 2>{}, x0, x1, f0, f1);
+    else if (k < gc.n_pad)
+        eval(std::integral_constant<int, 1>{}, x0, x0, f0, f0);
 }
 
 // Phase 2: the triangular products on the matrix cores.

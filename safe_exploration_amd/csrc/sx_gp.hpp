@@ -40,6 +40,74 @@ __device__ __forceinline__ int frag_index(int c, int k) {
     return (((k >> 3) * 64 + ((k & 3) << 4) + c) << 1) + ((k >> 2) & 1);
 }
 
+// 2^(j/128), j = 0..127, correctly rounded (generated with mpmath at 200 bits).
+__device__ const double kExp2Tab[128] = {
+    1.0, 1.0054299011128027, 1.0108892860517005, 1.016378314910953,
+    1.0218971486541166, 1.0274459491187637, 1.0330248790212284, 1.0386341019613787,
+    1.0442737824274138, 1.0499440858006872, 1.0556451783605572, 1.061377227289262,
+    1.0671404006768237, 1.0729348675259756, 1.0787607977571199, 1.0846183622133092,
+    1.0905077326652577, 1.0964290818163769, 1.102382583307841, 1.1083684117236787,
+    1.1143867425958924, 1.1204377524096067, 1.1265216186082418, 1.1326385195987192,
+    1.1387886347566916, 1.1449721444318042, 1.1511892299529827, 1.1574400736337511,
+    1.1637248587775775, 1.1700437696832502, 1.1763969916502812, 1.182784710984341,
+    1.189207115002721, 1.1956643920398273, 1.202156731452703, 1.2086843236265816,
+    1.215247359980469, 1.2218460329727576, 1.22848053610687, 1.2351510639369334,
+    1.241857812073484, 1.2486009771892048, 1.255380757024691, 1.2621973503942507,
+    1.2690509571917332, 1.275941778396392, 1.2828700160787783, 1.2898358734066657,
+    1.2968395546510096, 1.3038812651919358, 1.3109612115247644, 1.318079601266064,
+    1.3252366431597413, 1.3324325470831615, 1.339667524053303, 1.3469417862329458,
+    1.3542555469368927, 1.3616090206382248, 1.3690024229745905, 1.3764359707545302,
+    1.383909881963832, 1.3914243757719262, 1.3989796725383112, 1.4065759938190154,
+    1.4142135623730951, 1.4218926021691656, 1.42961333839197, 1.4373759974489824,
+    1.4451808069770467, 1.4530279958490526, 1.460917794180647, 1.4688504333369818,
+    1.4768261459394993, 1.4848451658727524, 1.4929077282912648, 1.5010140696264256,
+    1.5091644275934228, 1.5173590411982147, 1.5255981507445384, 1.533881997840956,
+    1.5422108254079407, 1.550584877685, 1.559004400237837, 1.567469639965553,
+    1.5759808451078865, 1.5845382652524937, 1.593142151342267, 1.6017927556826934,
+    1.6104903319492543, 1.6192351351948637, 1.6280274218573478, 1.6368674497669644,
+    1.645755478153965, 1.6546917676561943, 1.6636765803267364, 1.6727101796415966,
+    1.681792830507429, 1.6909247992693053, 1.7001063537185235, 1.709337763100463,
+    1.718619298122478, 1.7279512309618377, 1.7373338352737062, 1.746767386199169,
+    1.7562521603732995, 1.7657884359332727, 1.7753764925265212, 1.785016611318935,
+    1.7947090750031072, 1.804454167806624, 1.8142521755003989, 1.8241033854070534,
+    1.8340080864093424, 1.843966568958626, 1.8539791250833855, 1.864046048397789,
+    1.8741676341103, 1.8843441790323345, 1.8945759815869656, 1.9048633418176741,
+    1.9152065613971474, 1.925605943636125, 1.9360617934922943, 1.9465744175792332,
+    1.9571441241754002, 1.9677712232331759, 1.978456026387951, 1.9891988469672663,
+};
+
+// e^x for M finite arguments at once, table-driven: x = (128 n + j) ln2/128 + r, |r| <= ln2/256, so
+// e^x = 2^n T[j] (1 + r + r^2/2 + ... + r^5/120) with T in LDS (`tab`, 128 doubles): 15 VALU instructions and one LDS
+// read per value against 19 for the polynomial-only form below, error <= ~1 ulp (-inf / NaN give NaN; below e^-745
+// the result underflows to 0 like ldexp does).  The M chains advance in lock-step for the reason given below.
+template <int M>
+__device__ __forceinline__ void exp_tab_f64_n(const double (&x)[M], double (&out)[M], const double* tab) {
+    double m[M], r[M], t[M], p[M];
+    int mi[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) m[i] = __builtin_rint(x[i] * 184.6649652337873);
+#pragma unroll
+    for (int i = 0; i < M; ++i) asm("v_cvt_i32_f64 %0, %1" : "=v"(mi[i]) : "v"(m[i]));  // saturating, NaN -> 0
+#pragma unroll
+    for (int i = 0; i < M; ++i) t[i] = tab[mi[i] & 127];
+#pragma unroll
+    for (int i = 0; i < M; ++i) r[i] = fma(m[i], -0.00541521234663378, x[i]);  // exact: the constant has 21 trailing zero bits
+#pragma unroll
+    for (int i = 0; i < M; ++i) r[i] = fma(m[i], -1.4907929134926466e-12, r[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) p[i] = fma(r[i], 8.33333333333333333333e-03, 4.16666666666666666667e-02);
+#pragma unroll
+    for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 1.66666666666666666667e-01);
+#pragma unroll
+    for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 0.5);
+#pragma unroll
+    for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < M; ++i) p[i] = p[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < M; ++i) out[i] = ldexp(fma(t[i], p[i], t[i]), mi[i] >> 7);
+}
+
 // e^x for M finite arguments at once (here x <= ln(outputscale)): round-to-nearest range reduction x = n ln2 + r,
 // |r| <= ln2 / 2, degree-13 Taylor polynomial (truncation 4e-18), ldexp: 19 VALU instructions per value, error <= ~2 ulp
 // (-inf / NaN give NaN).  The M Horner chains advance in lock-step: a dependent f64 op issues every ~9 cycles, an
@@ -95,13 +163,15 @@ struct GpTileLds {
     double* mj;     // [NS][16 rows][16]  mean / Jacobian rows
     double* part;   // [NW][NS][16]       per-wave partial sums of squares
     double* zs;     // [16][D]            query points
+    double* etab;   // [128]              2^(j/128) for exp_tab_f64_n
     __device__ double* carve(double* base, int n_train, int n_pad, int nw) {
         xs = base;
         kfrag = xs + ((n_pad * D + 1) & ~1);
         mj = kfrag + (size_t)NS * n_pad * 16;
         part = mj + NS * 256;
         zs = part + (size_t)nw * NS * 16;
-        return zs + 16 * D;
+        etab = zs + 16 * D;
+        return etab + 128;
     }
 };
 
@@ -145,12 +215,13 @@ inline int gp_stage_cap(int ns, int n_pad, int nw) {
 inline int64_t gp_stage_tab_ints(int ns, int n_pad, int nw) { return 4 * (int64_t)nw * (1 + gp_stage_cap(ns, n_pad, nw)); }
 
 inline size_t gp_tile_lds_doubles(int ns, int d, int n_train, int n_pad, int nw) {
-    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d;
+    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d + 128;
 }
 
 template <int NS, int D>
 __device__ __forceinline__ void gp_load_xs(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds) {
     for (int i = threadIdx.x; i < gc.n_pad * D; i += blockDim.x) lds.xs[i] = i < gc.n_train * D ? gc.x_train[i] : 0.0;
+    if (threadIdx.x < 128) lds.etab[threadIdx.x] = kExp2Tab[threadIdx.x];
 }
 
 // Phase 1: Kstar_d[c][k] = s_d exp(-1/2 sum_j (z_cj - X_kj)^2 / l_dj^2) for the tile's 16 points, all k < n_pad, all d.
@@ -195,7 +266,7 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
                 arg[h * NS + d] = a;
             }
         }
-        exp_f64_n<M * NS>(arg, val);
+        exp_tab_f64_n<M * NS>(arg, val, lds.etab);
 #pragma unroll
         for (int h = 0; h < M; ++h) {
             double* f = h ? f1 : f0;
@@ -285,9 +356,34 @@ struct MfmaStage {
 
 #define SX_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// The W fragments of a wave's first three stages.  The stream is static, so a kernel loads them ONCE and keeps them
+// in registers: the L2 round trip that would otherwise open every MFMA phase is gone (-1 % per rollout step).
+struct MfmaHead {
+    v2d a[3][2];
+};
+
+template <int NS, int D>
+__device__ __forceinline__ MfmaHead gp_mfma_head(const GpConst<NS, D>& gc, const int4* __restrict__ stage_tab, int wave,
+                                                 int nw, int lane) {
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    // (a stream is followed by kStagePad valid dummy descriptors, so three stages can always be requested)
+    const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * gc.stage_cap;
+    const __amdgpu_buffer_rsrc_t arsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gc.a_pack), 0, (int)0xffffffffu, 0x00020000);
+    MfmaHead h;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int aoff = stages[i].x << 10;
+        h.a[i][0] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(arsrc, lane * 16, aoff, 0));
+        h.a[i][1] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(arsrc, lane * 16, aoff + 1024, 0));
+    }
+    return h;
+}
+
 template <int NS, int D>
 __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const int4* __restrict__ stage_tab,
-                                              GpTileLds<NS, D>& lds, int wave, int nw, int lane) {
+                                              GpTileLds<NS, D>& lds, int wave, int nw, int lane,
+                                              const MfmaHead& head) {
     double ssq[NS];
 #pragma unroll
     for (int d = 0; d < NS; ++d) ssq[d] = 0.0;
@@ -331,10 +427,10 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(arsrc, lane16, aoff + byte_off, 0);
         return __builtin_bit_cast(v2d, raw);
     };
-    auto issue = [&](MfmaStage& st, int i) {  // prologue form: no computing stage in front
+    auto issue = [&](MfmaStage& st, int i) {  // prologue form: the W fragments are resident (gp_mfma_head)
         decode(st, i);
-        st.a0 = load_a(0);
-        st.a1 = load_a(1024);
+        st.a0 = head.a[i][0];
+        st.a1 = head.a[i][1];
         st.b0 = bp[0];
         st.b1 = bp[64];
     };
@@ -360,7 +456,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         SX_PIN();
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.y, cur.b1.y, acc, 0, 0, 0);
         SX_PIN();
-        if (cur.w & kStageLast) {
+        if (__builtin_expect(cur.w & kStageLast, 0)) {  // unlikely: the common path falls through
             const int d = cur.z & 255;
             double s;
             if (cur.w & kStageExtra) {

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     gp_load_xs(gc, lds);
+    const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane);
     for (int tile = blockIdx.x; tile * SX_TILE < P; tile += gridDim.x) {
         const int g0 = tile * SX_TILE;
         if (tid < SX_TILE * D) {
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
         __syncthreads();
         gp_kstar_phase(gc, lds);
         __syncthreads();
-        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane);
+        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head);
         __syncthreads();
         if (tid < SX_TILE && g0 + tid < P) {
             double zz[D], m[NS], v[NS], jc[NS][D];

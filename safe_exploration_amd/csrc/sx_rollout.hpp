@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 #ifdef SX_STAMPS
     unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0, c_e = 0, c_eb = 0;
 #endif
+    const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane);
     for (int t = 0; t < H; ++t) {
 #ifdef SX_STAMPS
         const unsigned long long t0 = stamp();
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 #ifdef SX_STAMPS
         const unsigned long long t2 = stamp();
 #endif
-        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane);
+        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head);
 #ifdef SX_STAMPS
         const unsigned long long t3 = stamp();
 #endif

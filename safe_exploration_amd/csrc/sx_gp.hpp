@@ -81,7 +81,8 @@ __device__ const double kExp2Tab[128] = {
 // read per value against 19 for the polynomial-only form below, error <= ~1 ulp (-inf / NaN give NaN; below e^-745
 // the result underflows to 0 like ldexp does).  The M chains advance in lock-step for the reason given below.
 template <int M>
-__device__ __forceinline__ void exp_tab_f64_n(const double (&x)[M], double (&out)[M], const double* tab) {
+__device__ __forceinline__ void exp_tab_f64_n(const double (&x)[M], double (&out)[M],
+                                              const __attribute__((address_space(3))) double* tab) {
     double m[M], r[M], t[M], p[M];
     int mi[M];
 #pragma unroll
@@ -225,33 +226,50 @@ __device__ __forceinline__ void gp_load_xs(const GpConst<NS, D>& gc, GpTileLds<N
 }
 
 // Phase 1: Kstar_d[c][k] = s_d exp(-1/2 sum_j (z_cj - X_kj)^2 / l_dj^2) for the tile's 16 points, all k < n_pad, all d.
-// Run by threads [first, blockDim.x), both multiples of 64: a thread keeps the same query point c = tid & 15 for every
-// k it visits (threads below `first` are busy elsewhere -- the rollout's wave 0 finishes the previous step meanwhile).
+// The rows are dealt out in groups of 4 to `nworkers` waves (group g -> worker g % nworkers); the calling wave is
+// `worker` and handles 16 query points x 4 rows at a time (in the rollout not every wave is a worker: wave 0 finishes
+// the previous step meanwhile).
 //
 // The phase is bound by VALU issue, on the pipe the f64 MFMAs use too (tools/overlap_probe.hip), so what counts is the
 // instruction count per value.  Columns k >= n_train of W and of the mean/Jacobian rows are zero (pack_a_kernel), so the
 // padding entries of Kstar only have to be finite: they are computed like any other from the zero rows gp_load_xs
-// appends to X -- no index clamp, no select.  A thread visits k0, k0 + kstep, k0 + 2 kstep, ...; kstep is a multiple
-// of 4, so two visits on, k & 7 is the same and both the X row and the fragment slot move by a constant.
+// appends to X -- no index clamp, no select.  A thread visits k0, k0 + kstep, k0 + 2 kstep, ... with
+// kstep = 4 nworkers, so two visits on, k & 7 is the same and both the X row and the fragment slot move by a constant.
+// Kstar lives in LDS as [pair q = k >> 3][output d][lane = ((k & 3) << 4) + c][slot = (k >> 2) & 1]: one ds_read_b128
+// per lane feeds two MFMAs of one output, and the NS values a Kstar thread produces for one (c, k) are a constant
+// 1 KB apart (an immediate offset of the store).
+__device__ __forceinline__ int kfrag_index(int ns, int c, int k, int d) {
+    return ((((k >> 3) * ns + d) * 64 + ((k & 3) << 4) + c) << 1) + ((k >> 2) & 1);
+}
+
+typedef __attribute__((address_space(3))) double lds_f64;
+
 template <int NS, int D>
-__device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int first = 0) {
-    if ((int)threadIdx.x < first) return;
-    const int t = (int)threadIdx.x - first;
-    const int c = t & 15;
+__device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int nworkers,
+                                               int worker) {
+    const int lane = (int)threadIdx.x & 63;
+    const int c = lane & 15;
     double z[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) z[j] = lds.zs[c * D + j];
-    const int kstep = ((int)blockDim.x - first) >> 4;
-    const int dstride = gc.n_pad * 16;
-    const int k0 = t >> 4;
+    const int kstep = 4 * nworkers;
+    const int k0 = 4 * worker + (lane >> 4);
+    // loop invariants the compiler would otherwise re-materialise from SGPRs on every trip (VOP3 takes one SGPR)
+    double log_os[NS];
+#pragma unroll
+    for (int d = 0; d < NS; ++d) {
+        log_os[d] = gc.log_os[d];
+        asm volatile("" : "+v"(log_os[d]));
+    }
+    const lds_f64* etab = (const lds_f64*)lds.etab;
 
     // M = 1 or 2 training points of this thread at once: M NS independent exp chains in flight
-    auto eval = [&](auto mtag, const double* x0, const double* x1, double* f0, double* f1) {
+    auto eval = [&](auto mtag, const lds_f64* x0, const lds_f64* x1, lds_f64* f0, lds_f64* f1) {
         constexpr int M = decltype(mtag)::value;
         double arg[M * NS], val[M * NS];
 #pragma unroll
         for (int h = 0; h < M; ++h) {
-            const double* xr = h ? x1 : x0;
+            const lds_f64* xr = h ? x1 : x0;
             double sq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -260,29 +278,32 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
             }
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
-                double a = gc.log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2)
+                double a = log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2)
 #pragma unroll
                 for (int j = 0; j < D; ++j) a = fma(sq[j], gc.nh_ils2[d * D + j], a);
                 arg[h * NS + d] = a;
             }
         }
-        exp_tab_f64_n<M * NS>(arg, val, lds.etab);
+        exp_tab_f64_n<M * NS>(arg, val, etab);
 #pragma unroll
         for (int h = 0; h < M; ++h) {
-            double* f = h ? f1 : f0;
+            lds_f64* f = h ? f1 : f0;
 #pragma unroll
-            for (int d = 0; d < NS; ++d) f[d * dstride] = val[h * NS + d];
+            for (int d = 0; d < NS; ++d) f[d * 128] = val[h * NS + d];
         }
     };
 
-    const double* x0 = lds.xs + k0 * D;
-    const double* x1 = x0 + kstep * D;
-    double* f0 = lds.kfrag + frag_index(c, k0);
-    double* f1 = lds.kfrag + frag_index(c, k0 + kstep);
-    const int xadv = 2 * kstep * D, fadv = kstep * 32;
+    // 32-bit LDS pointers, advanced by a constant per trip and hidden from the optimiser, which would otherwise turn
+    // them back into base + offset and spend an add per access
+    const lds_f64* x0 = (const lds_f64*)lds.xs + k0 * D;
+    const lds_f64* x1 = x0 + kstep * D;
+    lds_f64* f0 = (lds_f64*)lds.kfrag + kfrag_index(NS, c, k0, 0);
+    lds_f64* f1 = (lds_f64*)lds.kfrag + kfrag_index(NS, c, k0 + kstep, 0);
+    const int xadv = 2 * kstep * D, fadv = kstep * NS * 32;
     // trips in which every thread has two points below n_pad: no conditions at all
     const int nfull = gc.n_pad / (2 * kstep);
     for (int trip = 0; trip < nfull; ++trip) {
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(f0), "+v"(f1));
         eval(std::integral_constant<int, 2>{}, x0, x1, f0, f1);
         x0 += xadv;
         x1 += xadv;
@@ -342,7 +363,7 @@ __device__ __forceinline__ void gp_build_stage_tab(int4* tab, int ns, int n_trai
         const int a0 = d * wpo + rb * (rb + 1);
         const int extra = (16 * rb + 15 >= n_train) ? kStageExtra : 0;  // block holds mean/Jacobian (or padding) rows
         for (int q = 0; q < npairs; q += 2, ++pos)
-            out[pos] = int4{a0 + q, d * n_pad * 8 + q * 64, d | (rb << 8), extra | ((q + 2 >= npairs) ? kStageLast : 0)};
+            out[pos] = int4{a0 + q, (q * ns + d) * 64, d | (rb << 8), extra | ((q + 2 >= npairs) ? kStageLast : 0)};
     }
     // dummy descriptors (valid addresses, never computed on) behind the stream
     for (int i = 0; i < kStagePad; ++i) out[pos + i] = int4{0, 0, 0, 0};
@@ -432,7 +453,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         st.a0 = head.a[i][0];
         st.a1 = head.a[i][1];
         st.b0 = bp[0];
-        st.b1 = bp[64];
+        st.b1 = bp[64 * NS];
     };
 
     // one accumulator: a dependent chain of this MFMA issues at the full rate (tools/mfma_probe.hip)
@@ -452,7 +473,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.x, cur.b1.x, acc, 0, 0, 0);
         SX_PIN();
         nx.b0 = bp[0];
-        nx.b1 = bp[64];
+        nx.b1 = bp[64 * NS];
         SX_PIN();
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.y, cur.b1.y, acc, 0, 0, 0);
         SX_PIN();

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
             lds.zs[tid] = (g0 + c < P) ? z[(int64_t)(g0 + c) * D + j] : 0.0;
         }
         __syncthreads();
-        gp_kstar_phase(gc, lds);
+        gp_kstar_phase(gc, lds, nw, wave);
         __syncthreads();
         gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head);
         __syncthreads();

@@ -185,11 +185,11 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
         const unsigned long long t0 = stamp();
 #endif
         if (t == 0) {
-            gp_kstar_phase(gc, lds);
+            gp_kstar_phase(gc, lds, nw, wave);
         } else if (wave == 0) {
             if (owner) finish(t - 1);
         } else {
-            gp_kstar_phase(gc, lds, 64);
+            gp_kstar_phase(gc, lds, nw - 1, wave - 1);
         }
 #ifdef SX_STAMPS
         const unsigned long long t1 = stamp();

@@ -377,27 +377,39 @@ struct MfmaStage {
 
 #define SX_PIN() __builtin_amdgcn_sched_barrier(0)
 
-// The W fragments of a wave's first three stages.  The stream is static, so a kernel loads them ONCE and keeps them
-// in registers: the L2 round trip that would otherwise open every MFMA phase is gone (-1 % per rollout step).
+// What a wave needs to open its MFMA phase: the stage count, the descriptors of its first four stages and the W
+// fragments of the first three.  The stream is static, so a kernel fetches all of it ONCE and keeps it in registers:
+// neither the scalar-load chain (header -> descriptor) nor the L2 round trip for W is paid per phase any more.
 struct MfmaHead {
     v2d a[3][2];
+    int nst;
+    int y[3], z[3], w[3];
+    int4 desc3;
 };
 
 template <int NS, int D>
 __device__ __forceinline__ MfmaHead gp_mfma_head(const GpConst<NS, D>& gc, const int4* __restrict__ stage_tab, int wave,
                                                  int nw, int lane) {
     const int swave = __builtin_amdgcn_readfirstlane(wave);
-    // (a stream is followed by kStagePad valid dummy descriptors, so three stages can always be requested)
+    // (a stream is followed by kStagePad valid dummy descriptors, so four stages can always be requested)
     const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * gc.stage_cap;
     const __amdgpu_buffer_rsrc_t arsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gc.a_pack), 0, (int)0xffffffffu, 0x00020000);
     MfmaHead h;
+    h.nst = __builtin_amdgcn_readfirstlane(stage_tab[swave].x);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int aoff = stages[i].x << 10;
+        const int4 dsc = stages[i];
+        const int aoff = dsc.x << 10;
         h.a[i][0] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(arsrc, lane * 16, aoff, 0));
         h.a[i][1] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(arsrc, lane * 16, aoff + 1024, 0));
+        h.y[i] = __builtin_amdgcn_readfirstlane(dsc.y);
+        h.z[i] = __builtin_amdgcn_readfirstlane(dsc.z);
+        h.w[i] = __builtin_amdgcn_readfirstlane(dsc.w);
     }
+    const int4 d3 = stages[3];
+    h.desc3 = int4{__builtin_amdgcn_readfirstlane(d3.x), __builtin_amdgcn_readfirstlane(d3.y),
+                   __builtin_amdgcn_readfirstlane(d3.z), __builtin_amdgcn_readfirstlane(d3.w)};
     return h;
 }
 
@@ -413,7 +425,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
     // stage_tab is a __restrict__ kernel argument of its own: the loads below are provably unclobbered and uniform,
     // which is what lets the compiler issue them as s_load
     const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * gc.stage_cap;
-    const int nst = stage_tab[swave].x;
+    const int nst = head.nst;
     // A fragments through a buffer descriptor: address = SGPR base + SGPR stage offset + constant per-lane offset,
     // so a load needs no vector arithmetic at all
     const __amdgpu_buffer_rsrc_t arsrc =
@@ -422,16 +434,9 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
     const v2d* kbase = reinterpret_cast<const v2d*>(lds.kfrag) + lane;
 
     // `desc` always holds the descriptor of the next stage to be issued, fetched one issue earlier.
-    int4 desc = stages[0];
+    int4 desc = head.desc3;
     int aoff;
     const v2d* bp;
-    auto decode = [&](MfmaStage& st, int inext) {
-        aoff = desc.x << 10;   // SGPR arithmetic
-        bp = kbase + desc.y;   // the one VALU op of a stage
-        st.z = desc.z;
-        st.w = desc.w;
-        desc = stages[inext + 1];
-    };
     // the same, split so that step() can spread it: an f64 MFMA leaves its wave only ~4 free issue slots
     // (tools/mfma_probe2.hip), so the ~13 non-MFMA instructions of a stage go 4 / 4 / 3 / 2 between the four MFMAs
     auto decode_a = [&](MfmaStage& st) {
@@ -448,12 +453,14 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(arsrc, lane16, aoff + byte_off, 0);
         return __builtin_bit_cast(v2d, raw);
     };
-    auto issue = [&](MfmaStage& st, int i) {  // prologue form: the W fragments are resident (gp_mfma_head)
-        decode(st, i);
+    auto issue = [&](MfmaStage& st, int i) {  // prologue form: everything but Kstar is resident (gp_mfma_head)
+        st.z = head.z[i];
+        st.w = head.w[i];
         st.a0 = head.a[i][0];
         st.a1 = head.a[i][1];
-        st.b0 = bp[0];
-        st.b1 = bp[64 * NS];
+        const v2d* b = kbase + head.y[i];
+        st.b0 = b[0];
+        st.b1 = b[64 * NS];
     };
 
     // one accumulator: a dependent chain of this MFMA issues at the full rate (tools/mfma_probe.hip)
@@ -525,12 +532,13 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
             }
         }
     }
+    // The four lanes l, l ^ 16, l ^ 32, l ^ 48 hold the partial sums of one query point.  Lane l's value is exactly the
+    // B operand element [k = l >> 4][col = l & 15], so ones(16 x 4) . B puts the column total into every lane: one
+    // more MFMA per output instead of two dependent cross-lane shuffles through LDS.
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
-        double v = ssq[d];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16) lds.part[(wave * NS + d) * 16 + lane] = v;
+        const v4d tot = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, ssq[d], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        if (lane < 16) lds.part[(wave * NS + d) * 16 + lane] = tot[0];
     }
 }
 

@@ -8,15 +8,20 @@
 namespace sx {
 
 // ---------------------------------------------------------------------------------------------------------------
-// sx_cem_rank_refit: one workgroup (16 waves) per problem.
+// sx_cem_rank_refit: one workgroup (16 waves) per problem.  The kernel is a chain of dependent steps on ONE compute
+// unit, so what it costs is workgroup barriers and LDS round trips, not arithmetic; every step below is built to
+// need one barrier.
 //   1. every thread keeps its candidates' 128-bit keys (con, obj) in registers: element i lives in slot i / 1024 of
 //      thread i % 1024, so (slot, thread) order is index order;
-//   2. MSB-first radix select of the k-th key, 8 bits per pass: wave-aggregated LDS histogram (one atomic per wave when
-//      all lanes agree -- the common case in the high bytes), bin scan by one wave, early exit as soon as the bin
-//      holding the k-th key is wholly selected;
-//   3. ballot compaction in index order (ties broken by the lower index); the best survivor is moved to the front,
-//      the others stay where the compaction put them (nothing downstream needs them sorted);
-//   4. refit: mean / unbiased std over the elites, rows spread over the whole workgroup.
+//   2. the best candidate (smallest (con, obj, index)) by one workgroup reduction;
+//   3. the k-th key: the constraint word takes few distinct values, so it is found by walking up the distinct values
+//      (counted with ballots); then MSB-first radix select on the objective word, 8 bits per pass, wave-aggregated LDS
+//      histograms in three rotating buffers (no clearing barrier), the bin scan done redundantly by every wave (no
+//      broadcast barrier), early exit as soon as the bin holding the k-th key is wholly selected;
+//   4. ballot compaction in index order (ties broken by the lower index) from one table of per-(slot, wave) counts
+//      that every wave scans itself; the best survivor goes to slot 0, the others keep their index order;
+//   5. refit: mean / unbiased std over the elites, rows spread over the whole workgroup, values kept in registers
+//      between the two passes.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRankThreads = 1024;
 constexpr int kRankWaves = kRankThreads / 64;
@@ -27,6 +32,16 @@ __device__ __forceinline__ unsigned long long sortable_key(double x) {
     if (x != x) return ~0ull;  // NaN last
     unsigned long long b = (unsigned long long)__double_as_longlong(x);
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
 }
 
 struct RankArgs {
@@ -46,14 +61,19 @@ struct RankArgs {
 
 template <int SLOTS>
 __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned long long sel_hi[kRankMaxK], sel_lo[kRankMaxK];
+    constexpr int kEntries = SLOTS * kRankWaves;  // (slot, wave) pairs, in index order
+    constexpr int EPL = kEntries / 64;            // table entries per lane when a wave scans the table
+    static_assert(SLOTS % 4 == 0, "a wave scans the (slot, wave) table with SLOTS / 4 entries per lane");
+    __shared__ unsigned int hist[3][256];
+    __shared__ unsigned long long red_h[kRankWaves], red_l[kRankWaves];
+    __shared__ int red_i[kRankWaves];
+    __shared__ unsigned long long walk_min[8];
+    __shared__ int walk_cnt[8];
+    __shared__ int cnt_less[kEntries], cnt_tie[kEntries];
+    __shared__ unsigned long long ball_less[kEntries], ball_tie[kEntries];
     __shared__ int sel_idx[kRankMaxK];
     __shared__ double red[kRankThreads];
     __shared__ double col_mean[256];
-    __shared__ int wave_cnt[kRankWaves][2];
-    __shared__ unsigned long long red_u64[kRankWaves], red_lo[kRankWaves];
-    __shared__ int sh_digit, sh_need, sh_done;
 
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
@@ -74,11 +94,46 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             kl[s] = sortable_key(obj[(long long)i * ra.cost_stride]);
         }
     }
+    if (tid < 256) {
+        hist[0][tid] = 0;
+        hist[1][tid] = 0;
+        hist[2][tid] = 0;
+    }
+    if (tid < 8) {
+        walk_min[tid] = ~0ull;
+        walk_cnt[tid] = 0;
+    }
 
 #ifdef SX_STAMPS
     const unsigned long long ts0 = stamp();
 #endif
-    // ---- radix select ----
+    // ---- the best candidate: smallest (con, obj, index) ----
+    unsigned long long bh = ~0ull, bl = ~0ull;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int i = s * kRankThreads + tid;
+        // (slots ascend in i, so an equal key never replaces an earlier one; the first valid candidate always enters,
+        // which keeps best_idx valid when every key is the NaN key)
+        if (i < P && (bi == 0x7fffffff || kh[s] < bh || (kh[s] == bh && kl[s] < bl))) { bh = kh[s]; bl = kl[s]; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long oh = __shfl_xor(bh, off), ol = __shfl_xor(bl, off);
+        const int oi = __shfl_xor(bi, off);
+        if (oh < bh || (oh == bh && (ol < bl || (ol == bl && oi < bi)))) { bh = oh; bl = ol; bi = oi; }
+    }
+    if (lane == 0) { red_h[wave] = bh; red_l[wave] = bl; red_i[wave] = bi; }
+    __syncthreads();  // (also publishes the cleared histograms / walk cells)
+#pragma unroll
+    for (int w = 0; w < kRankWaves; ++w) {
+        const unsigned long long oh = red_h[w], ol = red_l[w];
+        const int oi = red_i[w];
+        if (oh < bh || (oh == bh && (ol < bl || (ol == bl && oi < bi)))) { bh = oh; bl = ol; bi = oi; }
+    }
+    const int best_idx = bi;  // uniform
+
+    // ---- the k-th key ----
     unsigned long long ph = 0, pl = 0;   // prefix of the k-th key found so far (uniform)
     unsigned long long mh = 0, ml = 0;   // mask of the prefix bits
     int need = k;                        // rank of the k-th key among the candidates matching the prefix
@@ -86,53 +141,50 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     int first_pass = 0;
     {
         // The constraint word takes few distinct values (0 for every feasible particle, then 3 a + 10 b), so its
-        // k-th smallest value is found by walking up the distinct values: one (min, multiplicity) reduction per value,
-        // at most 8 of them, instead of eight radix passes.  (Beyond 8 the general passes below take over.)
-        unsigned long long floor_key = 0;  // only keys >= floor_key are still in play
-        int acc = 0;                       // candidates below floor_key
+        // k-th smallest value is found by walking up the distinct values, at most 8 of them (beyond that the general
+        // passes below take over).  The smallest one is the best candidate's; its multiplicity comes from ballots.
+        unsigned long long cur = bh;
+        int acc = 0;  // candidates below `cur`
         for (int it = 0; it < 8; ++it) {
-            unsigned long long mn = ~0ull;
+            if (it > 0) {
+                // next distinct value above the previous one
+                unsigned long long mn = ~0ull;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+                    if ((s * kRankThreads + tid < P) && kh[s] > cur && kh[s] < mn) mn = kh[s];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const unsigned long long om = __shfl_xor(mn, off);
+                    if (om < mn) mn = om;
+                }
+                if (lane == 0 && mn != ~0ull) atomicMin(&walk_min[it], mn);
+                __syncthreads();
+                cur = walk_min[it];
+                if (cur == ~0ull) break;  // no further value (cannot happen while acc < k <= P, kept for safety)
+            }
             int cnt = 0;
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const bool in_play = (s * kRankThreads + tid < P) && kh[s] >= floor_key;
-                if (in_play) {
-                    if (kh[s] < mn) { mn = kh[s]; cnt = 1; } else if (kh[s] == mn) { ++cnt; }
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long om = __shfl_xor(mn, off);
-                const int oc = __shfl_xor(cnt, off);
-                if (om < mn) { mn = om; cnt = oc; } else if (om == mn) { cnt += oc; }
-            }
-            if (lane == 0) { red_u64[wave] = mn; wave_cnt[wave][0] = cnt; }
+            for (int s = 0; s < SLOTS; ++s)
+                cnt += __popcll(__ballot((s * kRankThreads + tid < P) && kh[s] == cur));
+            if (lane == 0) atomicAdd(&walk_cnt[it], cnt);
             __syncthreads();
-            mn = red_u64[0];
-            cnt = wave_cnt[0][0];
-#pragma unroll
-            for (int w = 1; w < kRankWaves; ++w) {
-                const unsigned long long om = red_u64[w];
-                const int oc = wave_cnt[w][0];
-                if (om < mn) { mn = om; cnt = oc; } else if (om == mn) { cnt += oc; }
-            }
-            __syncthreads();
+            cnt = walk_cnt[it];
             if (acc + cnt >= k) {   // the k-th key has this constraint word
-                ph = mn;
+                ph = cur;
                 mh = ~0ull;
                 need = k - acc;
                 first_pass = 8;
                 break;
             }
             acc += cnt;
-            floor_key = mn + 1;
         }
     }
     for (int pass = first_pass; pass < 16 && !done; ++pass) {
         const int shift = 56 - 8 * (pass & 7);
         const bool in_hi = pass < 8;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
+        unsigned int* h = hist[pass % 3];
+        // the buffer of the next pass was last read two passes ago: clear it now, behind this pass's barrier
+        if (tid < 256) hist[(pass + 1) % 3][tid] = 0;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int i = s * kRankThreads + tid;
@@ -140,121 +192,105 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             const unsigned int digit = match ? (unsigned int)(((in_hi ? kh[s] : kl[s]) >> shift) & 255ull) : 0xffffffffu;
             const unsigned int first = __builtin_amdgcn_readfirstlane(digit);
             if (__all(digit == first)) {
-                if (first != 0xffffffffu && lane == 0) atomicAdd(&hist[first], 64u);
+                if (first != 0xffffffffu && lane == 0) atomicAdd(&h[first], 64u);
             } else if (match) {
-                atomicAdd(&hist[digit], 1u);
+                atomicAdd(&h[digit], 1u);
             }
         }
         __syncthreads();
-        if (wave == 0) {
-            // lane l owns bins 4l .. 4l+3
-            const unsigned int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
-            const int mine = (int)(c0 + c1 + c2 + c3);
-            int incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off);
-                if (lane >= off) incl += v;
-            }
-            const int before = incl - mine;
-            if (need > before && need <= incl) {
-                int rem = need - before;
-                int dsel = 4 * lane;
-                unsigned int cnt = c0;
-                if (rem > (int)c0) { rem -= c0; dsel++; cnt = c1;
-                    if (rem > (int)c1) { rem -= c1; dsel++; cnt = c2;
-                        if (rem > (int)c2) { rem -= c2; dsel++; cnt = c3; } } }
-                sh_digit = dsel;
-                sh_need = rem;
-                sh_done = (rem == (int)cnt) ? 1 : 0;  // the whole bin is selected: no need to look at lower digits
-            }
-        }
-        __syncthreads();
-        const unsigned long long dg = (unsigned long long)sh_digit << shift, mk = 255ull << shift;
+        // every wave scans the 256 bins itself: lane l owns bins 4l .. 4l+3
+        const unsigned int c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+        const int mine = (int)(c0 + c1 + c2 + c3);
+        const int incl = wave_incl_scan(mine, lane);
+        const int before = incl - mine;
+        const bool owner = need > before && need <= incl;  // exactly one lane
+        int rem = need - before;
+        int dsel = 4 * lane;
+        unsigned int cnt = c0;
+        if (rem > (int)c0) { rem -= c0; dsel++; cnt = c1;
+            if (rem > (int)c1) { rem -= c1; dsel++; cnt = c2;
+                if (rem > (int)c2) { rem -= c2; dsel++; cnt = c3; } } }
+        const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(owner)) - 1);
+        const int digit_sel = __builtin_amdgcn_readlane(dsel, src);
+        need = __builtin_amdgcn_readlane(rem, src);
+        done = __builtin_amdgcn_readlane((int)(rem == (int)cnt), src) != 0;  // whole bin selected: lower digits do not matter
+        const unsigned long long dg = (unsigned long long)digit_sel << shift, mk = 255ull << shift;
         if (in_hi) { ph |= dg; mh |= mk; } else { pl |= dg; ml |= mk; }
-        need = sh_need;
-        done = sh_done != 0;
     }
 #ifdef SX_STAMPS
     const unsigned long long ts1 = stamp();
 #endif
+    // ---- compaction ----
     // Candidates whose masked key is below the prefix are selected; of those equal to it, the first `need` in index
     // order (all of them after an early exit).
     const int n_less_total = k - need;
-    int base_less = 0, base_tie = 0;
+    unsigned long long my_bl[SLOTS], my_bt[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        if (s * kRankThreads >= P) break;
         const int i = s * kRankThreads + tid;
         const unsigned long long a_h = kh[s] & mh, a_l = kl[s] & ml;
         const bool valid = i < P;
         const bool less = valid && (a_h < ph || (a_h == ph && a_l < pl));
         const bool tie = valid && a_h == ph && a_l == pl;
-        const unsigned long long bl = __ballot(less), bt = __ballot(tie);
+        my_bl[s] = __ballot(less);
+        my_bt[s] = __ballot(tie);
         if (lane == 0) {
-            wave_cnt[wave][0] = __popcll(bl);
-            wave_cnt[wave][1] = __popcll(bt);
+            cnt_less[s * kRankWaves + wave] = __popcll(my_bl[s]);
+            cnt_tie[s * kRankWaves + wave] = __popcll(my_bt[s]);
+            ball_less[s * kRankWaves + wave] = my_bl[s];
+            ball_tie[s * kRankWaves + wave] = my_bt[s];
         }
-        __syncthreads();
-        int off_less = base_less, off_tie = base_tie, tot_less = 0, tot_tie = 0;
-#pragma unroll
-        for (int w = 0; w < kRankWaves; ++w) {
-            const int cl = wave_cnt[w][0], ct = wave_cnt[w][1];
-            if (w < wave) { off_less += cl; off_tie += ct; }
-            tot_less += cl;
-            tot_tie += ct;
-        }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (less) {
-            const int slot = off_less + __popcll(bl & below);
-            sel_hi[slot] = kh[s]; sel_lo[slot] = kl[s]; sel_idx[slot] = i;
-        } else if (tie) {
-            const int r = off_tie + __popcll(bt & below);
-            if (r < need) {
-                const int slot = n_less_total + r;
-                sel_hi[slot] = kh[s]; sel_lo[slot] = kl[s]; sel_idx[slot] = i;
-            }
-        }
-        base_less += tot_less;
-        base_tie += tot_tie;
-        __syncthreads();
     }
+    __syncthreads();
+    // exclusive prefix over the (slot, wave) table, by every wave for itself: lane l holds entries EPL l .. EPL l + EPL-1
+    int tl[EPL], tt[EPL], sum_l = 0, sum_t = 0;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        tl[j] = cnt_less[EPL * lane + j];
+        tt[j] = cnt_tie[EPL * lane + j];
+        sum_l += tl[j];
+        sum_t += tt[j];
+    }
+    const int ex_l = wave_incl_scan(sum_l, lane) - sum_l, ex_t = wave_incl_scan(sum_t, lane) - sum_t;
+    auto table_offset = [&](const int (&cell)[EPL], int ex, int entry) {  // entry is wave-uniform
+        const int src = __builtin_amdgcn_readfirstlane(entry / EPL), sub = entry % EPL;
+        int off = __builtin_amdgcn_readlane(ex, src);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if (j < sub) off += __builtin_amdgcn_readlane(cell[j], src);
+        return off;
+    };
+    // where the best candidate would land: it goes to slot 0 instead, those in front of it move up by one
+    int best_slot;
+    {
+        const bool best_less = ((bh & mh) < ph) || ((bh & mh) == ph && (bl & ml) < pl);
+        const int bs = best_idx / kRankThreads, bt = best_idx % kRankThreads;
+        const int entry = bs * kRankWaves + (bt >> 6);
+        const unsigned long long before = (1ull << (bt & 63)) - 1ull;
+        if (best_less)
+            best_slot = table_offset(tl, ex_l, entry) + __popcll(ball_less[entry] & before);
+        else  // it matches the prefix (after an early exit the ties differ in their lower bits: it need not be the first)
+            best_slot = n_less_total + table_offset(tt, ex_t, entry) + __popcll(ball_tie[entry] & before);
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        if (s * kRankThreads >= P) break;
+        const int i = s * kRankThreads + tid;
+        const int entry = s * kRankWaves + wave;
+        int slot = -1;
+        if ((my_bl[s] >> lane) & 1ull) {
+            slot = table_offset(tl, ex_l, entry) + __popcll(my_bl[s] & below);
+        } else if ((my_bt[s] >> lane) & 1ull) {
+            const int r = table_offset(tt, ex_t, entry) + __popcll(my_bt[s] & below);
+            if (r < need) slot = n_less_total + r;
+        }
+        if (slot >= 0) sel_idx[slot == best_slot ? 0 : (slot < best_slot ? slot + 1 : slot)] = i;
+    }
+    __syncthreads();
 #ifdef SX_STAMPS
     const unsigned long long ts2 = stamp();
-#endif
-    // ---- the elites stay where the compaction put them; only the best one is moved to the front ----
-    {
-        unsigned long long bh = ~0ull, bl = ~0ull;
-        int bi = 0x7fffffff, bslot = 0;
-        for (int i = tid; i < k; i += kRankThreads) {
-            const unsigned long long h = sel_hi[i], l = sel_lo[i];
-            const int ix = sel_idx[i];
-            if (h < bh || (h == bh && (l < bl || (l == bl && ix < bi)))) { bh = h; bl = l; bi = ix; bslot = i; }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long oh = __shfl_xor(bh, off), ol = __shfl_xor(bl, off);
-            const int oi = __shfl_xor(bi, off), os = __shfl_xor(bslot, off);
-            if (oh < bh || (oh == bh && (ol < bl || (ol == bl && oi < bi)))) { bh = oh; bl = ol; bi = oi; bslot = os; }
-        }
-        if (lane == 0) { red_u64[wave] = bh; red_lo[wave] = bl; wave_cnt[wave][0] = bi; wave_cnt[wave][1] = bslot; }
-        __syncthreads();
-        if (tid == 0) {
-            int best_w = 0;
-            for (int w = 1; w < kRankWaves; ++w) {
-                const unsigned long long oh = red_u64[w], ol = red_lo[w], ch = red_u64[best_w], cl = red_lo[best_w];
-                if (oh < ch || (oh == ch && (ol < cl || (ol == cl && wave_cnt[w][0] < wave_cnt[best_w][0])))) best_w = w;
-            }
-            const int s = wave_cnt[best_w][1];
-            const unsigned long long th = sel_hi[0], tl = sel_lo[0];
-            const int ti = sel_idx[0];
-            sel_hi[0] = sel_hi[s]; sel_lo[0] = sel_lo[s]; sel_idx[0] = sel_idx[s];
-            sel_hi[s] = th; sel_lo[s] = tl; sel_idx[s] = ti;
-        }
-        __syncthreads();
-    }
-#ifdef SX_STAMPS
-    const unsigned long long ts3 = stamp();
+    const unsigned long long ts3 = ts2;
 #endif
     // ---- outputs ----
     const int L = ra.row_len;
@@ -276,18 +312,29 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         }
     }
     if (ra.best)
-        for (int c = tid; c < L; c += kRankThreads) ra.best[(long long)e * L + c] = act[(long long)sel_idx[0] * ra.act_stride + c];
-    if (ra.best_ok && tid == 0) ra.best_ok[e] = (con[(long long)sel_idx[0] * ra.cost_stride] == 0.0) ? 1 : 0;
+        for (int c = tid; c < L; c += kRankThreads) ra.best[(long long)e * L + c] = act[(long long)best_idx * ra.act_stride + c];
+    if (ra.best_ok && tid == 0) ra.best_ok[e] = (con[(long long)best_idx * ra.cost_stride] == 0.0) ? 1 : 0;
     if (ra.mean) {
-        // columns in chunks of up to 256; thread t sums rows t / Lc, t / Lc + R, ... of column t % Lc
+        // columns in chunks of up to 256; thread t sums rows t / Lc, t / Lc + R, ... of column t % Lc and keeps the first
+        // kKeep values it loaded for the second pass
+        constexpr int kKeep = 8;
         for (int c0 = 0; c0 < L; c0 += 256) {
             const int Lc = (L - c0) < 256 ? (L - c0) : 256;
             const int R = kRankThreads / Lc;  // row groups
             const int c = tid % Lc, r0 = tid / Lc;
             const bool active = r0 < R;
+            double keep[kKeep];
             double s = 0.0;
-            if (active)
-                for (int r = r0; r < k; r += R) s += act[(long long)sel_idx[r] * ra.act_stride + c0 + c];
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < kKeep; ++j) {
+                    const int r = r0 + j * R;
+                    keep[j] = (r < k) ? act[(long long)sel_idx[r] * ra.act_stride + c0 + c] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < kKeep; ++j) s += keep[j];
+                for (int r = r0 + kKeep * R; r < k; r += R) s += act[(long long)sel_idx[r] * ra.act_stride + c0 + c];
+            }
             red[tid] = s;
             __syncthreads();
             if (tid < Lc) {
@@ -298,12 +345,18 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             __syncthreads();
             const double mu = col_mean[c];
             double ss = 0.0;
-            if (active)
-                for (int r = r0; r < k; r += R) {
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < kKeep; ++j) {
+                    const double dv = keep[j] - mu;
+                    if (r0 + j * R < k) ss += dv * dv;
+                }
+                for (int r = r0 + kKeep * R; r < k; r += R) {
                     const double dv = act[(long long)sel_idx[r] * ra.act_stride + c0 + c] - mu;
                     ss += dv * dv;
                 }
-            red[tid] = ss;
+            }
+            red[tid] = ss;  // (the column owners finished reading red before the barrier above)
             __syncthreads();
             if (tid < Lc) {
                 double t = 0.0;

@@ -204,6 +204,25 @@ class FusedCemMpc:
             distributed.all_reduce_max_(status, self._group)
         return out['best'].view(E, H, n_u), out['best_ok'], history, status
 
+    def get_actions_batch(self, states: Tensor) -> Tuple[Tensor, Tensor, List[Rollouts]]:
+        """E independent episodes at once (BASELINE config 5): flat start states [E x (n_s + n_s^2)], all
+        points.  One fused solve: the kernels carry the episode dimension, episodes never exchange anything.
+
+        Returns (actions [E x H x n_u], found bool [E] on the host, rollouts); ``found[e] == False`` is the
+        ``get_actions`` ``None`` of episode e.  Raises like ``get_actions`` if any episode hit a numerical failure.
+        """
+        n_s = self._ssm.num_states
+        if states.dim() != 2 or states.size(1) != n_s + n_s * n_s:
+            raise ValueError(f'Wanted shape (E, {n_s + n_s * n_s}), got {tuple(states.shape)}')
+        if bool((states[:, n_s:] != 0).any()):
+            raise NotImplementedError('get_actions_batch starts from point states (all-zero Q), as CemSafeMPC.get_action does')
+        x0 = states[:, :n_s].to(self._device, torch.float64).contiguous()
+        best, best_ok, history, status = self.solve(x0)
+        flags = torch.cat((status, best_ok)).cpu()   # the one device->host hand-off of the batch
+        self.last_status = int(flags[0])
+        raise_for_status(self.last_status, 'get_actions_batch')
+        return best, flags[1:] != 0, history
+
     def get_actions(self, state: Tensor) -> Tuple[Optional[Tensor], List[Rollouts]]:
         """state: the flat start state [1 x (n_s + n_s^2)] with an all-zero Q block (a point, safempc_cem.py:234-235)."""
         n_s = self._ssm.num_states

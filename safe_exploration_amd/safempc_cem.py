@@ -204,6 +204,8 @@ class CemSafeMPC(SafeMPC):
         self._mpc = mpc
         self._last_mpc_actions = np.empty((0, self.action_dimen))
         self._mpc_actions_executed = 0
+        self._batch_last_actions: Optional[List[ndarray]] = None   # per-episode ladder state of get_action_batch
+        self._batch_executed: Optional[List[int]] = None
         self.last_rollouts: List[Rollouts] = []
 
     # ---- the reference's read-only members -----------------------------------------------------------------------
@@ -296,6 +298,43 @@ class CemSafeMPC(SafeMPC):
             action = self._safe_policy(state)
             result = MpcResult.SAFE_CONTROLLER
         return action, result
+
+    def get_action_batch(self, states: ndarray) -> Tuple[ndarray, List[MpcResult]]:
+        """``get_action`` for E independent episodes in lockstep (BASELINE config 5): states [E x n_s] ->
+        (actions [E x n_u], one MpcResult per episode).  One fused solve serves all episodes; each episode keeps its own
+        PREVIOUS_SOLUTION / SAFE_CONTROLLER ladder (reference safempc_cem.py:243-263).  The episode count is fixed by the
+        first call (``reset_batch`` starts over)."""
+        states = np.asarray(states)
+        if states.ndim != 2 or states.shape[1] != self._state_dimen:
+            raise ValueError(f'Wanted shape (E, {self._state_dimen}), got {states.shape}')
+        E = states.shape[0]
+        if self._batch_last_actions is None or len(self._batch_last_actions) != E:
+            self._batch_last_actions = [np.empty((0, self.action_dimen)) for _ in range(E)]
+            self._batch_executed = [0] * E
+        state_batch = torch.tensor(states, device=self._device)
+        best, found, rollouts = self._solver().get_actions_batch(self._pq_flattener.flatten(state_batch, None))
+        best = best.detach().cpu().numpy()
+        self.last_rollouts = rollouts
+        actions: List[ndarray] = []
+        results: List[MpcResult] = []
+        for e in range(E):
+            if bool(found[e]):
+                self._batch_last_actions[e] = best[e]
+                self._batch_executed[e] = 1
+                actions.append(best[e][0])
+                results.append(MpcResult.FOUND_SOLUTION)
+            elif self._batch_executed[e] < self._batch_last_actions[e].shape[0]:
+                actions.append(self._batch_last_actions[e][self._batch_executed[e]])
+                self._batch_executed[e] += 1
+                results.append(MpcResult.PREVIOUS_SOLUTION)
+            else:
+                actions.append(np.asarray(self._safe_policy(states[e])))
+                results.append(MpcResult.SAFE_CONTROLLER)
+        return np.stack(actions), results
+
+    def reset_batch(self) -> None:
+        self._batch_last_actions = None
+        self._batch_executed = None
 
     def get_action_verbose(self, state: ndarray):
         raise NotImplementedError

@@ -498,3 +498,31 @@ def test_other_state_action_dimensions(n_s, n_u):
     np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
     assert int(r['status'].item()) == ref.status == 0
     assert (ref.con_cost > 0).any()
+
+
+def test_batched_episodes_equal_single_solves():
+    """SURVEY 8f-2 / BASELINE config 5: E episodes in one fused solve give, episode by episode, exactly what E separate
+    solves give with the same noise (episodes never exchange anything)."""
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.cem_mpc import FusedCemMpc
+    spec = problems.pendulum(n_train=60)
+    ssm, env = problems.build(spec, 'cuda:0')
+    E, P, H, k, iters = 5, 512, 6, 40, 4
+    g = torch.Generator(device='cuda:0')
+    g.manual_seed(11)
+    noise = torch.randn((iters, E, P, H, 1), dtype=torch.float64, device='cuda:0', generator=g)
+    x0 = torch.tensor([[0.02, -0.03], [0.0, 0.0], [-0.05, 0.1], [0.1, 0.2], [0.6, 3.0]], dtype=torch.float64, device='cuda:0')
+    mpc = FusedCemMpc(ssm, env, H, P, k, iters, device='cuda:0', init_std=0.2)
+    best, ok, _, status = mpc.solve(x0, noise=noise)
+    assert int(status.item()) == 0
+    for e in range(E):
+        b1, ok1, _, st1 = mpc.solve(x0[e:e + 1], noise=noise[:, e:e + 1].contiguous())
+        assert int(ok1[0]) == int(ok[e])
+        torch.testing.assert_close(b1[0], best[e], rtol=0, atol=0)
+    # and through the reference-shaped surface: flat point states in, per-episode found flags out
+    flat = torch.cat((x0, torch.zeros((E, 4), dtype=torch.float64, device='cuda:0')), dim=1)
+    acts, found, _ = mpc.get_actions_batch(flat)
+    assert tuple(acts.shape) == (E, H, 1) and found.dtype == torch.bool and len(found) == E
+    assert bool(found[0]) and not bool(found[4])   # the last start state is far outside the safe polytope
+    with pytest.raises(ValueError):
+        mpc.get_actions_batch(flat[:, :5])

@@ -163,6 +163,48 @@ class TestFallbackLadder:   # test_safempc_cem.py:74-148
             s.get_action_verbose(np.zeros(2))
 
 
+class TestBatchedEpisodes:   # the ladder of test_safempc_cem.py:74-148, one per episode
+    def test_each_episode_has_its_own_ladder(self):
+        mpc = mock.Mock()
+        sol = torch.tensor([[[0.1], [0.2]], [[0.5], [0.6]], [[0.0], [0.0]]])
+        mpc.get_actions_batch.side_effect = [
+            (sol, torch.tensor([True, True, False]), []),        # episode 2 never finds anything
+            (sol + 1, torch.tensor([False, True, False]), []),   # episode 0 falls back on its previous solution
+            (sol + 2, torch.tensor([False, False, False]), []),  # episode 0 has run out, episode 1 falls back
+        ]
+        s, _ = _solver(mpc)
+        s._safe_policy = lambda x: np.array([x[0]])
+        states = np.array([[0., 0.], [1., 1.], [3., 4.]])
+        a, r = s.get_action_batch(states)
+        assert r == [MpcResult.FOUND_SOLUTION, MpcResult.FOUND_SOLUTION, MpcResult.SAFE_CONTROLLER]
+        np.testing.assert_allclose(a[0], [0.1]); np.testing.assert_allclose(a[1], [0.5])
+        flat = mpc.get_actions_batch.call_args[0][0]
+        assert tuple(flat.shape) == (3, 6) and bool((flat[:, 2:] == 0).all())
+        a, r = s.get_action_batch(states)
+        assert r == [MpcResult.PREVIOUS_SOLUTION, MpcResult.FOUND_SOLUTION, MpcResult.SAFE_CONTROLLER]
+        np.testing.assert_allclose(a[0], [0.2]); np.testing.assert_allclose(a[1], [1.5])
+        a, r = s.get_action_batch(states)
+        assert r == [MpcResult.SAFE_CONTROLLER, MpcResult.PREVIOUS_SOLUTION, MpcResult.SAFE_CONTROLLER]
+        np.testing.assert_allclose(a[1], [1.6])
+
+    def test_safe_policy_gets_the_episodes_own_state(self):
+        mpc = mock.Mock()
+        mpc.get_actions_batch.return_value = (torch.zeros((2, 2, 1)), torch.tensor([False, False]), [])
+        ssm = mock.Mock()
+        ssm.x_train = None
+        s = CemSafeMPC(ssm, [], FakePendulum(), FakeConfig(), {'lin_model': ([0.1, 0.2])}, wx_feedback_cost=None,
+                       wu_feedback_cost=None, lqr=mock.Mock(), mpc=mpc, beta_safety=1.0,
+                       safe_policy=lambda x: np.array([x[0] + 10 * x[1]]))
+        a, r = s.get_action_batch(np.array([[1., 2.], [3., 4.]]))
+        assert r == [MpcResult.SAFE_CONTROLLER] * 2
+        np.testing.assert_allclose(a, [[21.], [43.]])
+
+    def test_bad_shape(self):
+        s, _ = _solver(mock.Mock())
+        with pytest.raises(ValueError):
+            s.get_action_batch(np.zeros((2, 3)))
+
+
 def test_objective_spec_mapping():
     mode, w_abs, tgt, w_lin = objective_spec(FakePendulum(False))
     assert mode == _lib.SX_OBJ_NEG_VARIANCE

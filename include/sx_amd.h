@@ -127,6 +127,13 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
 int sx_gp_predict(const sx_gp_model* model, const double* z, int P, double* mean, double* var, double* jac,
                   void* workspace, int64_t workspace_bytes, void* stream);
 
+/* d var / d z at z dev [P x D]: jac_var dev [P x n_s x D]; `linv` dev [n_s x N x N] as produced by sx_gp_fit for this model.
+ * Not on the CEM path: it completes the numpy adapter (StateSpaceModel.predict(..., jacobians=True) returns it as its
+ * fourth output).  Replaces: compute_jacobian(pred_var, inp) in GPyTorchSSM._predict
+ * (ssm_pytorch/gaussian_process.py:222-231). */
+int sx_gp_predict_var_jac(const sx_gp_model* model, const double* linv, const double* z, int P, double* jac_var,
+                          void* stream);
+
 /* Bytes of workspace sx_gp_predict needs (0 while the training set fits the single-launch kernel; < 0 = bad arguments). */
 int64_t sx_gp_predict_workspace_bytes(const sx_gp_model* model, int P);
 

@@ -64,6 +64,19 @@ class ExactGP:
                 jac[:, d, :] = (w @ self.X - w.sum(1)[:, None] * z) / (self.ls[d] ** 2)[None, :]
         return mean, var, jac
 
+    def variance_jacobian(self, z):
+        """d var_d / d z_j = 2 sum_i v_i k*_i (z_j - X_ij) / l_dj^2 with v = (K_d + noise_d I)^-1 k*   [P x n_s x D].
+        (The reference differentiates gpytorch's variance with autograd, ssm_pytorch/gaussian_process.py:222-231;
+        closed form here, pinned by finite differences of `predict` in tests/test_oracle_golden.py.)"""
+        z = np.asarray(z, dtype=np.float64)
+        out = np.empty((z.shape[0], self.n_s, self.D))
+        for d in range(self.n_s):
+            ks = self.kernel(d, z, self.X)                                  # [P x N]
+            v = sla.cho_solve((self.L[d], True), ks.T).T                    # [P x N]
+            w = v * ks
+            out[:, d, :] = 2.0 * (w.sum(1)[:, None] * z - w @ self.X) / (self.ls[d] ** 2)[None, :]
+        return out
+
     # the operands the HIP kernels consume (checked against the device-side fit in tests)
     def linv(self):
         """[n_s x N x N] inverse Cholesky factors W_d = L_d^-1 (lower triangular)."""

@@ -272,4 +272,73 @@ __global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad
     if ((int)threadIdx.x < nw) gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_predict_var_jac: d var_d / d z for the numpy StateSpaceModel adapter (the casadi-based solvers linearise the
+// variance; the CEM path never needs it).  var_d = s_d + noise_d - k*^T (K_d + noise_d I)^-1 k*, so
+//     d var_d / d z_j = 2 sum_i v_i k*_i (z_j - X_ij) / l_dj^2,      v = W_d^T (W_d k*).
+// One workgroup per (query point, output); W_d streamed twice (rows for t = W k*, columns for v = W^T t).
+// ---------------------------------------------------------------------------------------------------------------
+struct VarJacArgs {
+    double inv_ls2[SX_MAX_NS * SX_MAX_D];
+    double outputscale[SX_MAX_NS];
+    const double* x;     // [N x D]
+    const double* linv;  // [n_s x N x N]
+    const double* z;     // [P x D]
+    double* jac_var;     // [P x n_s x D]
+    int n, D, n_s;
+};
+
+__global__ __launch_bounds__(256) void gp_var_jac_kernel(VarJacArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double vj_smem[];
+    double* ks = vj_smem;        // [N]  k*
+    double* ts = vj_smem + a.n;  // [N]  t = W k*
+    __shared__ double red[4][SX_MAX_D];
+    const int p = blockIdx.x, d = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int n = a.n, D = a.D;
+    const double* W = a.linv + (size_t)d * n * n;
+    double z[SX_MAX_D], w2[SX_MAX_D];
+    for (int j = 0; j < D; ++j) {
+        z[j] = a.z[(size_t)p * D + j];
+        w2[j] = a.inv_ls2[d * D + j];
+    }
+    for (int i = tid; i < n; i += blockDim.x) {
+        double q = 0.0;
+        for (int j = 0; j < D; ++j) {
+            const double df = z[j] - a.x[(size_t)i * D + j];
+            q += df * df * w2[j];
+        }
+        ks[i] = a.outputscale[d] * exp(-0.5 * q);
+    }
+    __syncthreads();
+    for (int r = wave; r < n; r += nwaves) {  // a wave per row: coalesced along the row
+        double s = 0.0;
+        for (int i = lane; i <= r; i += 64) s += W[(size_t)r * n + i] * ks[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) ts[r] = s;
+    }
+    __syncthreads();
+    double g[SX_MAX_D];
+    for (int j = 0; j < D; ++j) g[j] = 0.0;
+    for (int i = tid; i < n; i += blockDim.x) {  // a thread per column: coalesced across the threads
+        double v = 0.0;
+        for (int r = i; r < n; ++r) v += W[(size_t)r * n + i] * ts[r];
+        const double w = v * ks[i];
+        for (int j = 0; j < D; ++j) g[j] += w * (z[j] - a.x[(size_t)i * D + j]) * w2[j];
+    }
+    for (int j = 0; j < D; ++j) {
+        double s = g[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) red[wave][j] = s;
+    }
+    __syncthreads();
+    if (tid < D) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += red[w][tid];
+        a.jac_var[((size_t)p * a.n_s + d) * D + tid] = 2.0 * s;
+    }
+}
+
 }  // namespace sx

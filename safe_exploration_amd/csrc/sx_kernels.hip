@@ -506,6 +506,34 @@ int sx_gp_mll_grad(const sx_gp_model* model, const double* y_train, const double
     return sx::check_launch();
 }
 
+int sx_gp_predict_var_jac(const sx_gp_model* model, const double* linv, const double* z, int P, double* jac_var,
+                          void* stream) {
+    if (!model || P < 0) return SX_ERR_ARG;
+    if (P == 0) return SX_OK;
+    if (!model->x_train || !linv || !z || !jac_var) return SX_ERR_ARG;
+    if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)
+        return SX_ERR_ARG;
+    const size_t lds = 2 * (size_t)model->n_train * sizeof(double);
+    if (lds > 128 * 1024) return SX_ERR_UNSUPPORTED;  // N <= 8192
+    sx::VarJacArgs va;
+    std::memset(&va, 0, sizeof(va));
+    const int D = model->n_s + model->n_u;
+    for (int i = 0; i < model->n_s * D; ++i) va.inv_ls2[i] = model->inv_ls2[i];
+    for (int i = 0; i < model->n_s; ++i) va.outputscale[i] = model->outputscale[i];
+    va.x = model->x_train;
+    va.linv = linv;
+    va.z = z;
+    va.jac_var = jac_var;
+    va.n = model->n_train;
+    va.D = D;
+    va.n_s = model->n_s;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)sx::gp_var_jac_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SX_ERR_LAUNCH;
+    hipLaunchKernelGGL(sx::gp_var_jac_kernel, dim3(P, model->n_s), dim3(256), lds, (hipStream_t)stream, va);
+    return sx::check_launch();
+}
+
 int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void* stream) {
     if (!model || !linv || !alpha || !model->x_train || !model->a_pack || !model->stage_tab) return SX_ERR_ARG;
     if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)

@@ -48,6 +48,7 @@ class GpCemSSM(CemSSM):
         self._buffers = ()  # keeps the device operands alive while the struct points at them
         self._workspace: Optional[Tensor] = None
         self._fit_ws = None
+        self._linv_current = False   # does _fit_ws[1] hold W of the CURRENT model?
 
     # ---- hyper-parameters --------------------------------------------------------------------------------------
     @property
@@ -102,6 +103,7 @@ class GpCemSSM(CemSSM):
             self._fit_ws = (torch.empty((n_s, n, n), dtype=torch.float64, device=dev),
                             torch.empty((n_s, n, n), dtype=torch.float64, device=dev))
         work, linv = self._fit_ws
+        self._linv_current = False   # (set again by _update_model, whose fit is the model's)
         alpha = torch.empty((n_s, n), dtype=torch.float64, device=dev)
         logdet = torch.empty((n_s,), dtype=torch.float64, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -130,6 +132,7 @@ class GpCemSSM(CemSSM):
         self._model = m
         self._buffers = (x, a_pack, stage_tab)
         self._alpha = alpha
+        self._linv_current = True
         # 1/2 log det(I + K_d / noise_d) = sum log diag L_d - N/2 log noise_d
         self._info_gain = (logdet.cpu() - 0.5 * n * torch.log(self.noise)).numpy()
 
@@ -226,6 +229,25 @@ class GpCemSSM(CemSSM):
     def predict_without_jacobians(self, states: Tensor, actions: Tensor) -> Tuple[Tensor, Tensor]:
         mean, var, _ = self._predict_z(self._join_states_actions(states, actions), False)
         return mean, var
+
+    def predict_variance_jacobian(self, states: Tensor, actions: Tensor) -> Tensor:
+        """d var / d (state, action)  [N x n_s x (n_s + n_u)].  Not used by the CEM solver; the numpy adapter
+        (state_space_models.HipGpStateSpaceModel) returns it where the reference's GPyTorchSSM returns
+        ``compute_jacobian(pred_var, inp)`` (ssm_pytorch/gaussian_process.py:222-231)."""
+        z = self._join_states_actions(states, actions)
+        n, d_in = z.size(0), self.num_states + self.num_actions
+        _lib.require_gpu(z, 'states/actions')
+        z = z.detach().contiguous()
+        out = torch.zeros((n, self.num_states, d_in), dtype=torch.float64, device=z.device)
+        if n == 0 or self._model is None:   # the prior variance does not depend on z
+            return out
+        if not self._linv_current:
+            # the fit workspace was reused since (hyper-parameter training): factorise once more
+            self._fit(self._x_train.detach().contiguous(), self._y_train.detach().contiguous())
+            self._linv_current = True
+        _lib.check(_lib.lib().sx_gp_predict_var_jac(ctypes.byref(self._model), _lib.ptr(self._fit_ws[1]), _lib.ptr(z), n,
+                                                   _lib.ptr(out), _lib.stream_ptr(z.device)), 'sx_gp_predict_var_jac')
+        return out
 
     def predict_raw(self, z: Tensor) -> Tuple[Tensor, Tensor]:
         mean, var, _ = self._predict_z(z, False)

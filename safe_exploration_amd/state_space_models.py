@@ -59,8 +59,11 @@ class HipGpStateSpaceModel(StateSpaceModel):
             raise NotImplementedError('full covariance between query points is not computed on this path')
         states, actions = np.atleast_2d(states), np.atleast_2d(actions)
         if jacobians:
-            mean, var, jac = self._ssm.predict_with_jacobians(self._t(states), self._t(actions))
-            return mean.cpu().numpy(), var.cpu().numpy(), jac.cpu().numpy()
+            # (mean, var, jac_mean, jac_var) like GPyTorchSSM._predict (ssm_pytorch/gaussian_process.py:222-231)
+            st, ac = self._t(states), self._t(actions)
+            mean, var, jac = self._ssm.predict_with_jacobians(st, ac)
+            jac_var = self._ssm.predict_variance_jacobian(st, ac)
+            return mean.cpu().numpy(), var.cpu().numpy(), jac.cpu().numpy(), jac_var.cpu().numpy()
         mean, var = self._ssm.predict_without_jacobians(self._t(states), self._t(actions))
         return mean.cpu().numpy(), var.cpu().numpy()
 

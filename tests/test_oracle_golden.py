@@ -139,6 +139,14 @@ def test_gp_structure():
         mp, _, _ = gp.predict(z + dz, False)
         mm, _, _ = gp.predict(z - dz, False)
         np.testing.assert_allclose(j[:, :, c], (mp - mm) / (2 * eps), rtol=1e-5, atol=1e-8)
+    gp2 = ExactGP(X, Y, ls, [0.7, 1.1], [1e-2, 3e-2])   # variance Jacobian: closed form == numeric
+    jv = gp2.variance_jacobian(z)
+    assert jv.shape == (7, 2, 3)
+    for c in range(3):
+        dz = np.zeros(3); dz[c] = eps
+        _, vp, _ = gp2.predict(z + dz, False)
+        _, vm, _ = gp2.predict(z - dz, False)
+        np.testing.assert_allclose(jv[:, :, c], (vp - vm) / (2 * eps), rtol=1e-5, atol=1e-8)
 
 
 def test_action_constraint_known_answer():

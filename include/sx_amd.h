@@ -111,10 +111,11 @@ int sx_gp_fit(const sx_gp_model* model, const double* y_train, double* work, dou
 
 /* Exact marginal log likelihood per output and its gradient w.r.t. the hyper-parameters, from sx_gp_fit's outputs:
  * mll dev [n_s]; grad dev [n_s x (D + 2)] = d mll_d / d (lengthscale_d[0..D), outputscale_d, noise_d).
+ * work dev [n_s x N x N]: scratch, overwritten (sx_gp_fit's `work` may be passed: L is not needed any more).
  * Replaces: the autograd pass of GpCemSSM._train_model (ssm_cem/gp_ssm_cem.py:103-129,
  * gpytorch.ExactMarginalLogLikelihood); the Adam update itself stays on the host. */
 int sx_gp_mll_grad(const sx_gp_model* model, const double* y_train, const double* linv, const double* alpha,
-                   const double* logdet, double* mll, double* grad, void* stream);
+                   const double* logdet, double* work, double* mll, double* grad, void* stream);
 
 /* Lays W_d = L_d^-1 (dev [n_s x N x N], lower triangular) and alpha (dev [n_s x N]) out in fragment order.
  * model->{n_s,n_u,n_train,inv_ls2,x_train,a_pack,stage_tab} must be set; n_pad is filled in.

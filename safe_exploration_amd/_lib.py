@@ -45,7 +45,7 @@ SIGNATURES = {
     'sx_version': (c_char_p, []),
     'sx_gp_pack_sizes': (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     'sx_gp_fit': (c_int, [POINTER(SxGpModel)] + [c_void_p] * 7),
-    'sx_gp_mll_grad': (c_int, [POINTER(SxGpModel)] + [c_void_p] * 7),
+    'sx_gp_mll_grad': (c_int, [POINTER(SxGpModel)] + [c_void_p] * 8),
     'sx_gp_pack': (c_int, [POINTER(SxGpModel), c_void_p, c_void_p, c_void_p]),
     'sx_gp_predict': (c_int, [POINTER(SxGpModel), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                               c_void_p]),

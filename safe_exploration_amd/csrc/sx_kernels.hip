@@ -10,6 +10,7 @@
 #include "sx_reach.hpp"
 #include "sx_big.hpp"
 #include "sx_fit.hpp"
+#include "sx_fit_blocked.hpp"
 #include "sx_rollout.hpp"
 #include "sx_rank.hpp"
 
@@ -453,6 +454,39 @@ int sx_gp_fit(const sx_gp_model* model, const double* y_train, double* work, dou
         fa.outputscale[i] = model->outputscale[i];
         fa.noise[i] = model->noise[i];
     }
+    if (model->n_train > sx::kBlockedFitMinN) {
+        // blocked multi-workgroup path (sx_fit_blocked.hpp)
+        sx::BlockedFitArgs ba;
+        std::memset(&ba, 0, sizeof(ba));
+        std::memcpy(ba.inv_ls2, fa.inv_ls2, sizeof(ba.inv_ls2));
+        std::memcpy(ba.outputscale, fa.outputscale, sizeof(ba.outputscale));
+        std::memcpy(ba.noise, fa.noise, sizeof(ba.noise));
+        ba.x = model->x_train;
+        ba.y = y_train;
+        ba.lmat = work;
+        ba.linv = linv;
+        ba.alpha = alpha;
+        ba.logdet = logdet;
+        ba.status = status;
+        ba.n = model->n_train;
+        ba.D = D;
+        ba.n_s = model->n_s;
+        ba.nblk = (ba.n + sx::kFB - 1) / sx::kFB;
+        hipStream_t s = (hipStream_t)stream;
+        const int nb = ba.nblk, ns = ba.n_s;
+        hipLaunchKernelGGL(sx::fit_kmat_kernel, dim3(nb, nb, ns), dim3(sx::kFThreads), 0, s, ba);
+        for (int p = 0; p < nb; ++p) {
+            hipLaunchKernelGGL(sx::fit_potrf_diag_kernel, dim3(ns), dim3(sx::kFThreads), 0, s, ba, p);
+            const int m = nb - p - 1;
+            if (m > 0) {
+                hipLaunchKernelGGL(sx::fit_trsm_kernel, dim3(m, ns), dim3(sx::kFThreads), 0, s, ba, p);
+                hipLaunchKernelGGL(sx::fit_syrk_kernel, dim3(m, m, ns), dim3(sx::kFThreads), 0, s, ba, p);
+            }
+        }
+        hipLaunchKernelGGL(sx::fit_trtri_kernel, dim3(nb, ns), dim3(sx::kFThreads), 0, s, ba);
+        hipLaunchKernelGGL(sx::fit_alpha_logdet_kernel, dim3(ns), dim3(1024), sizeof(double) * (size_t)ba.n, s, ba);
+        return sx::check_launch();
+    }
     fa.x = model->x_train;
     fa.y = y_train;
     fa.lmat = work;
@@ -480,10 +514,32 @@ int sx_gp_fit(const sx_gp_model* model, const double* y_train, double* work, dou
 }
 
 int sx_gp_mll_grad(const sx_gp_model* model, const double* y_train, const double* linv, const double* alpha,
-                   const double* logdet, double* mll, double* grad, void* stream) {
-    if (!model || !model->x_train || !y_train || !linv || !alpha || !logdet || !mll || !grad) return SX_ERR_ARG;
+                   const double* logdet, double* work, double* mll, double* grad, void* stream) {
+    if (!model || !model->x_train || !y_train || !linv || !alpha || !logdet || !work || !mll || !grad) return SX_ERR_ARG;
     if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)
         return SX_ERR_ARG;
+    if (model->n_train > sx::kBlockedFitMinN) {
+        sx::BlockedMllArgs ba;
+        std::memset(&ba, 0, sizeof(ba));
+        const int Db = model->n_s + model->n_u;
+        for (int i = 0; i < model->n_s * Db; ++i) ba.inv_ls2[i] = model->inv_ls2[i];
+        for (int i = 0; i < model->n_s; ++i) ba.outputscale[i] = model->outputscale[i];
+        ba.x = model->x_train;
+        ba.y = y_train;
+        ba.linv = linv;
+        ba.alpha = alpha;
+        ba.logdet = logdet;
+        ba.scratch = work;
+        ba.mll = mll;
+        ba.grad = grad;
+        ba.n = model->n_train;
+        ba.D = Db;
+        ba.n_s = model->n_s;
+        ba.nblk = (ba.n + sx::kFB - 1) / sx::kFB;
+        hipLaunchKernelGGL(sx::mll_pairs_kernel, dim3(ba.nblk, ba.nblk, ba.n_s), dim3(sx::kFThreads), 0, (hipStream_t)stream, ba);
+        hipLaunchKernelGGL(sx::mll_reduce_kernel, dim3(ba.n_s), dim3(256), 0, (hipStream_t)stream, ba);
+        return sx::check_launch();
+    }
     sx::MllArgs ma;
     std::memset(&ma, 0, sizeof(ma));
     const int D = model->n_s + model->n_u;

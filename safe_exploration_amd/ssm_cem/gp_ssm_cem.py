@@ -145,7 +145,8 @@ class GpCemSSM(CemSSM):
         mll = torch.empty((self.num_states,), dtype=torch.float64, device=x.device)
         grad = torch.empty((self.num_states, d_in + 2), dtype=torch.float64, device=x.device)
         _lib.check(_lib.lib().sx_gp_mll_grad(ctypes.byref(m), _lib.ptr(y), _lib.ptr(linv), _lib.ptr(alpha), _lib.ptr(logdet),
-                                             _lib.ptr(mll), _lib.ptr(grad), _lib.stream_ptr(x.device)), 'sx_gp_mll_grad')
+                                             _lib.ptr(self._fit_ws[0]), _lib.ptr(mll), _lib.ptr(grad),
+                                             _lib.stream_ptr(x.device)), 'sx_gp_mll_grad')
         host = torch.cat((mll, grad.reshape(-1), status.double())).cpu()
         if int(host[-1]) & _lib.SX_STATUS_NOT_PD:
             raise RuntimeError('the kernel matrix K + noise I is not positive definite for the current hyper-parameters')

@@ -164,10 +164,14 @@ def test_fused_rollout_costs_vs_oracle(P, H, obj_mode):
     np.testing.assert_allclose(actions, mean[None] + std[None] * noise, rtol=1e-13, atol=1e-16)
     ref = ocem.rollout(prob, gp, x0, actions)
     traj = r['traj'][0].cpu().numpy()
-    np.testing.assert_allclose(traj[:, :, :2], ref.traj_p, rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(traj[:, :, 2:].reshape(P, H, 2, 2), ref.traj_q, rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(r['sigma'][0].cpu().numpy(), ref.sigma, rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(r['obj_cost'][0].cpu().numpy(), ref.obj_cost, rtol=1e-8, atol=1e-11)
+    # Tolerance: 1e-8 relative over short chains.  Over 15 steps the ellipsoids of this problem grow by orders of
+    # magnitude and the rounding difference between the device's blocked Cholesky and LAPACK's (~1e-16 x cond(K), K with
+    # noise 1e-5) is amplified to ~1e-8: 1e-7 there.
+    rtol = 1e-8 if H <= 7 else 1e-7
+    np.testing.assert_allclose(traj[:, :, :2], ref.traj_p, rtol=rtol, atol=1e-11)
+    np.testing.assert_allclose(traj[:, :, 2:].reshape(P, H, 2, 2), ref.traj_q, rtol=rtol, atol=1e-11)
+    np.testing.assert_allclose(r['sigma'][0].cpu().numpy(), ref.sigma, rtol=rtol, atol=1e-11)
+    np.testing.assert_allclose(r['obj_cost'][0].cpu().numpy(), ref.obj_cost, rtol=rtol, atol=1e-11)
     np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
     if H <= 7:  # long horizons are infeasible for this problem (ellipsoids outgrow the polytope): only costs there
         assert (ref.con_cost > 0).any() and (ref.con_cost == 0).any()

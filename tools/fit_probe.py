@@ -8,6 +8,7 @@ for which, n in (('pendulum', 200), ('pendulum', 590), ('cartpole', 2000)):
     spec = getattr(problems, which)(n_train=n)
     ssm, env = problems.build(spec, dev)
     x, y = ssm.x_train, ssm.y_train
+    ssm._update_model(x, y); ssm.mll_and_grad(x, y)   # warm-up: code objects load on first launch
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3): ssm._update_model(x, y)

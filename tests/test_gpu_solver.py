@@ -531,3 +531,23 @@ def test_batched_episodes_equal_single_solves():
     assert bool(found[0]) and not bool(found[4])   # the last start state is far outside the safe polytope
     with pytest.raises(ValueError):
         mpc.get_actions_batch(flat[:, :5])
+
+
+@pytest.mark.parametrize('n', [40, 96, 97, 128, 200, 333])
+def test_fit_products_vs_oracle(n):
+    """sx_gp_fit (one-workgroup kernel up to N = 96, blocked matrix-core path beyond; N on and off the 64-block grid):
+    W = L^-1, alpha, sum log diag L against numpy/LAPACK."""
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-1, 1, size=(n, 3))
+    Y = np.stack([np.sin(2 * X[:, 0]) + X[:, 2], X[:, 1] ** 2], 1) + 0.05 * rng.normal(size=(n, 2))
+    ls, s, nz = rng.uniform(0.5, 1.5, size=(2, 3)), np.array([0.8, 1.3]), np.array([2e-2, 5e-3])
+    ssm = GpCemSSM(Conf(), 2, 1)
+    ssm.set_hyperparameters(ls, s, nz)
+    m, linv, alpha, logdet, status = ssm._fit(T(X), T(Y))
+    assert int(status.item()) == 0
+    gp = ExactGP(X, Y, ls, s, nz)
+    np.testing.assert_allclose(np.tril(linv.cpu().numpy()), gp.linv(), rtol=1e-9, atol=1e-10)
+    assert not np.triu(linv.cpu().numpy(), 1).any()          # strictly upper part: zeros
+    np.testing.assert_allclose(alpha.cpu().numpy(), np.stack(gp.alpha), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(logdet.cpu().numpy(), [np.log(np.diag(L)).sum() for L in gp.L], rtol=1e-12)

@@ -4,7 +4,7 @@ Mirrors the surface of the reference's ``safe_exploration/ssm_cem/ssm_cem.py:11-
 works with the other.
 """
 from abc import ABC, abstractmethod
-from typing import Any, Dict, Optional, Tuple
+from typing import Any, Callable, Dict, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -80,3 +80,66 @@ class CemSSM(ABC):
     @abstractmethod
     def parametric(self) -> bool:
         ...
+
+
+class JunkDimensionsSSM(CemSSM):
+    """Wraps an SSM, padding every call with zero-valued junk state / action dimensions (the reference's way of trying
+    an SSM in a higher-dimensional setting, ssm_cem/ssm_cem.py:134-210; created by utils_config._create_cem_ssm:46-47).
+
+    Mirrors the reference exactly, including where the junk goes: states -> [states, junk], actions -> [actions, junk],
+    raw inputs -> [z, all junk]; outputs are cut back to the leading real dimensions (the Jacobian to its leading
+    n_s + n_u columns, as the reference does).  It works with any CemSSM at this surface -- the HIP-backed GpCemSSM as
+    long as the padded sizes stay within its limits (n_s <= 4, n_u <= 2); the fused CEM solver itself takes a GpCemSSM.
+    """
+
+    def __init__(self, constructor: Callable[..., CemSSM], state_dimen: int, action_dimen: int, junk_states: int,
+                 junk_actions: int):
+        super().__init__(state_dimen, action_dimen)
+        self._junk_states = junk_states
+        self._junk_actions = junk_actions
+        self._ssm = constructor(state_dimen=state_dimen + junk_states, action_dimen=action_dimen + junk_actions)
+
+    def predict_with_jacobians(self, states: Tensor, actions: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        means, variances, jacs = self._ssm.predict_with_jacobians(
+            self._expand(states, self.num_states, self._junk_states),
+            self._expand(actions, self.num_actions, self._junk_actions))
+        return (means[:, :self.num_states], variances[:, :self.num_states],
+                jacs[:, :self.num_states, :(self.num_states + self.num_actions)])
+
+    def predict_without_jacobians(self, states: Tensor, actions: Tensor) -> Tuple[Tensor, Tensor]:
+        means, variances = self._ssm.predict_without_jacobians(
+            self._expand(states, self.num_states, self._junk_states),
+            self._expand(actions, self.num_actions, self._junk_actions))
+        return means[:, :self.num_states], variances[:, :self.num_states]
+
+    def predict_raw(self, z: Tensor) -> Tuple[Tensor, Tensor]:
+        means, variances = self._ssm.predict_raw(
+            self._expand(z, self.num_states + self.num_actions, self._junk_states + self._junk_actions))
+        return means[:, :self.num_states], variances[:, :self.num_states]
+
+    def update_model(self, train_x: Tensor, train_y: Tensor, opt_hyp=False, replace_old=False) -> None:
+        super().update_model(train_x, train_y, opt_hyp, replace_old)
+        self._ssm.update_model(
+            self._expand(train_x, self.num_states + self.num_actions, self._junk_states + self._junk_actions),
+            self._expand(train_y, self.num_states, self._junk_states), opt_hyp, replace_old)
+
+    @staticmethod
+    def _expand(x: Tensor, real_dimen: int, junk_dimen: int) -> Tensor:
+        n = x.size(0)
+        assert_shape(x, (n, real_dimen))
+        expanded = torch.zeros((n, real_dimen + junk_dimen), device=x.device, dtype=x.dtype)
+        expanded[:, :real_dimen] = x
+        return expanded
+
+    def _update_model(self, x_train: Tensor, y_train: Tensor) -> None:
+        pass
+
+    def _train_model(self, x_train: Tensor, y_train: Tensor) -> None:
+        pass
+
+    def collect_metrics(self) -> Dict[str, Any]:
+        return self._ssm.collect_metrics()
+
+    @property
+    def parametric(self) -> bool:
+        return self._ssm.parametric

@@ -551,3 +551,32 @@ def test_fit_products_vs_oracle(n):
     assert not np.triu(linv.cpu().numpy(), 1).any()          # strictly upper part: zeros
     np.testing.assert_allclose(alpha.cpu().numpy(), np.stack(gp.alpha), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(logdet.cpu().numpy(), [np.log(np.diag(L)).sum() for L in gp.L], rtol=1e-12)
+
+
+def test_junk_dimensions_wrapper_over_the_hip_gp():
+    """JunkDimensionsSSM(GpCemSSM) (reference utils_config.py:46-47): 2 + 1 real dimensions padded to the 4 + 2 the HIP GP
+    supports == the oracle GP on the zero-padded inputs, cut back the way the reference cuts."""
+    import functools
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+    from safe_exploration_amd.ssm_cem.ssm_cem import JunkDimensionsSSM
+    rng = np.random.default_rng(21)
+    n = 70
+    X = rng.uniform(-1, 1, size=(n, 3))
+    Y = np.stack([np.sin(2 * X[:, 0]) + X[:, 2], X[:, 1] ** 2], 1)
+    ssm = JunkDimensionsSSM(functools.partial(GpCemSSM, Conf()), state_dimen=2, action_dimen=1, junk_states=2, junk_actions=1)
+    ls, s, nz = rng.uniform(0.6, 1.4, size=(4, 6)), rng.uniform(0.5, 1.0, size=4), np.full(4, 1e-3)
+    ssm._ssm.set_hyperparameters(ls, s, nz)
+    ssm.update_model(T(X), T(Y), replace_old=True)
+    Xp = np.concatenate((X, np.zeros((n, 3))), 1)            # raw inputs: [z, all junk]   (ssm_cem.py:186-187)
+    Yp = np.concatenate((Y, np.zeros((n, 2))), 1)
+    gp = ExactGP(Xp, Yp, ls, s, nz)
+    z = rng.uniform(-1, 1, size=(11, 3))
+    mean, var, jac = ssm.predict_with_jacobians(T(z[:, :2]), T(z[:, 2:]))
+    zq = np.zeros((11, 6))
+    zq[:, :2], zq[:, 4:5] = z[:, :2], z[:, 2:]               # queries: [states, junk] + [actions, junk]   (:160-161)
+    mo, vo, jo = gp.predict(zq)
+    np.testing.assert_allclose(mean.cpu().numpy(), mo[:, :2], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(var.cpu().numpy(), vo[:, :2], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(jac.cpu().numpy(), jo[:, :2, :3], rtol=1e-9, atol=1e-12)   # leading columns, as the reference
+    m2, v2 = ssm.predict_without_jacobians(T(z[:, :2]), T(z[:, 2:]))
+    assert torch.equal(m2, mean) and tuple(v2.shape) == (11, 2)

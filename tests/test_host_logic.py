@@ -300,3 +300,47 @@ def test_shard_particles_and_seeds():
         assert [o for _, o in counts] == list(np.cumsum([0] + [c for c, _ in counts])[:-1])
     assert distributed.rank_seed(1, 0) != distributed.rank_seed(1, 1)
     assert distributed.world_and_rank(None) == (1, 0)
+
+
+class TestJunkDimensionsSSM:   # test_ssm_cem.py:116-168
+    @staticmethod
+    def _wrapped(**returns):
+        from safe_exploration_amd.ssm_cem.ssm_cem import JunkDimensionsSSM
+        inner = mock.Mock()
+        for name, value in returns.items():
+            getattr(inner, name).return_value = value
+        constructor = mock.Mock(return_value=inner)
+        ssm = JunkDimensionsSSM(constructor, state_dimen=2, action_dimen=1, junk_states=5, junk_actions=20)
+        assert constructor.call_args[1] == {'state_dimen': 7, 'action_dimen': 21}
+        return ssm, inner
+
+    def test_predict_with_jacobians_expands_dimensions(self):
+        ssm, inner = self._wrapped(predict_with_jacobians=(torch.empty((3, 7)), torch.empty((3, 7)), torch.empty((3, 7, 28))))
+        means, variances, jacs = ssm.predict_with_jacobians(torch.ones((3, 2)), torch.ones((3, 1)))
+        assert means.size() == (3, 2) and variances.size() == (3, 2) and jacs.size() == (3, 2, 3)
+        (call_states, call_actions), _ = inner.predict_with_jacobians.call_args
+        assert call_states.size() == (3, 7) and call_actions.size() == (3, 21)
+        assert bool((call_states[:, :2] == 1).all()) and bool((call_states[:, 2:] == 0).all())   # junk is zero-valued
+
+    def test_predict_without_jacobians_expands_dimensions(self):
+        ssm, inner = self._wrapped(predict_without_jacobians=(torch.empty((3, 7)), torch.empty((3, 7))))
+        means, variances = ssm.predict_without_jacobians(torch.empty((3, 2)), torch.empty((3, 1)))
+        assert means.size() == (3, 2) and variances.size() == (3, 2)
+        (call_states, call_actions), _ = inner.predict_without_jacobians.call_args
+        assert call_states.size() == (3, 7) and call_actions.size() == (3, 21)
+
+    def test_predict_raw_expands_dimensions(self):
+        ssm, inner = self._wrapped(predict_raw=(torch.empty((3, 7)), torch.empty((3, 7))))
+        means, variances = ssm.predict_raw(torch.empty((3, 3)))
+        assert means.size() == (3, 2) and variances.size() == (3, 2)
+        (call_z,), _ = inner.predict_raw.call_args
+        assert call_z.size() == (3, 28)
+
+    def test_update_model_pads_and_keeps_the_real_data(self):
+        ssm, inner = self._wrapped()
+        ssm.update_model(torch.ones((4, 3)), torch.ones((4, 2)), opt_hyp=True, replace_old=True)
+        x, y, opt_hyp, replace_old = inner.update_model.call_args[0]
+        assert x.size() == (4, 28) and y.size() == (4, 7) and opt_hyp and replace_old
+        assert ssm.x_train.size() == (4, 3) and ssm.y_train.size() == (4, 2)
+        with pytest.raises(ValueError):
+            ssm.predict_raw(torch.empty((3, 4)))

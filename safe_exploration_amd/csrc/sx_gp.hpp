@@ -76,25 +76,32 @@ __device__ const double kExp2Tab[128] = {
     1.9571441241754002, 1.9677712232331759, 1.978456026387951, 1.9891988469672663,
 };
 
-// e^x for M finite arguments at once, table-driven: x = (128 n + j) ln2/128 + r, |r| <= ln2/256, so
-// e^x = 2^n T[j] (1 + r + r^2/2 + ... + r^5/120) with T in LDS (`tab`, 128 doubles): 15 VALU instructions and one LDS
-// read per value against 19 for the polynomial-only form below, error <= ~1 ulp (-inf / NaN give NaN; below e^-745
-// the result underflows to 0 like ldexp does).  The M chains advance in lock-step for the reason given below.
+constexpr double kExpScale = 128.0 / 0.693147180559945309417232;   // 128 / ln 2
+constexpr double kExpUnit = 0.693147180559945309417232 / 128.0;    // ln 2 / 128
+
+// e^x for M arguments at once, table-driven; the caller passes y = x * 128 / ln 2 (it folds the factor into the
+// constants that produce x).  y = 128 n + j + f, |f| <= 1/2, so e^x = 2^n T[j] e^r with r = f ln2/128, |r| <= ln2/256:
+// T from LDS (`tab`, 128 doubles), e^r - 1 by a degree-5 polynomial.  15 VALU instructions and one LDS read per value
+// against 19 for the polynomial-only form below; error <= ~1 ulp on top of the rounding of y itself (|x| 2e-16, the
+// same as rounding x would cost).  Below e^-800 the result is 0 whatever the argument (also -inf, also 1e300
+// lengthscales away): the clamp keeps the reduction exact for every input.  A NaN argument does NOT give NaN (max
+// drops it): callers that must propagate NaN pass a table of NaNs (gp_kstar_phase does).  The M chains advance in
+// lock-step for the reason given below.
 template <int M>
-__device__ __forceinline__ void exp_tab_f64_n(const double (&x)[M], double (&out)[M],
+__device__ __forceinline__ void exp_tab_f64_n(const double (&y)[M], double (&out)[M],
                                               const __attribute__((address_space(3))) double* tab) {
-    double m[M], r[M], t[M], p[M];
+    double m[M], r[M], t[M], p[M], yc[M];
     int mi[M];
 #pragma unroll
-    for (int i = 0; i < M; ++i) m[i] = __builtin_rint(x[i] * 184.6649652337873);
+    for (int i = 0; i < M; ++i) yc[i] = __builtin_fmax(y[i], -800.0 * kExpScale);
 #pragma unroll
-    for (int i = 0; i < M; ++i) asm("v_cvt_i32_f64 %0, %1" : "=v"(mi[i]) : "v"(m[i]));  // saturating, NaN -> 0
+    for (int i = 0; i < M; ++i) m[i] = __builtin_rint(yc[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) asm("v_cvt_i32_f64 %0, %1" : "=v"(mi[i]) : "v"(m[i]));
 #pragma unroll
     for (int i = 0; i < M; ++i) t[i] = tab[mi[i] & 127];
 #pragma unroll
-    for (int i = 0; i < M; ++i) r[i] = fma(m[i], -0.00541521234663378, x[i]);  // exact: the constant has 21 trailing zero bits
-#pragma unroll
-    for (int i = 0; i < M; ++i) r[i] = fma(m[i], -1.4907929134926466e-12, r[i]);
+    for (int i = 0; i < M; ++i) r[i] = (yc[i] - m[i]) * kExpUnit;   // the difference is exact
 #pragma unroll
     for (int i = 0; i < M; ++i) p[i] = fma(r[i], 8.33333333333333333333e-03, 4.16666666666666666667e-02);
 #pragma unroll
@@ -146,6 +153,8 @@ struct GpConst {
     double inv_ls2[NS * D];
     double nh_ils2[NS * D];   // -1 / (2 l^2)
     double log_os[NS];        // ln(outputscale)
+    double k_nh_ils2[NS * D];  // the same two, times 128 / ln 2: the fused Kstar phase computes the exponent in units of
+    double k_log_os[NS];       // ln 2 / 128 (exp_tab_f64_n)
     double outputscale[NS];
     double noise[NS];
     const double* x_train;
@@ -164,7 +173,7 @@ struct GpTileLds {
     double* mj;     // [NS][16 rows][16]  mean / Jacobian rows
     double* part;   // [NW][NS][16]       per-wave partial sums of squares
     double* zs;     // [16][D]            query points
-    double* etab;   // [128]              2^(j/128) for exp_tab_f64_n
+    double* etab;   // [256]              2^(j/128) for exp_tab_f64_n, then 128 NaNs (the table of a NaN query point)
     __device__ double* carve(double* base, int n_train, int n_pad, int nw) {
         xs = base;
         kfrag = xs + ((n_pad * D + 1) & ~1);
@@ -172,7 +181,7 @@ struct GpTileLds {
         part = mj + NS * 256;
         zs = part + (size_t)nw * NS * 16;
         etab = zs + 16 * D;
-        return etab + 128;
+        return etab + 256;
     }
 };
 
@@ -216,13 +225,16 @@ inline int gp_stage_cap(int ns, int n_pad, int nw) {
 inline int64_t gp_stage_tab_ints(int ns, int n_pad, int nw) { return 4 * (int64_t)nw * (1 + gp_stage_cap(ns, n_pad, nw)); }
 
 inline size_t gp_tile_lds_doubles(int ns, int d, int n_train, int n_pad, int nw) {
-    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d + 128;
+    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d + 256;
 }
 
 template <int NS, int D>
 __device__ __forceinline__ void gp_load_xs(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds) {
     for (int i = threadIdx.x; i < gc.n_pad * D; i += blockDim.x) lds.xs[i] = i < gc.n_train * D ? gc.x_train[i] : 0.0;
-    if (threadIdx.x < 128) lds.etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    if (threadIdx.x < 128) {
+        lds.etab[threadIdx.x] = kExp2Tab[threadIdx.x];
+        lds.etab[128 + threadIdx.x] = __builtin_nan("");
+    }
 }
 
 // Phase 1: Kstar_d[c][k] = s_d exp(-1/2 sum_j (z_cj - X_kj)^2 / l_dj^2) for the tile's 16 points, all k < n_pad, all d.
@@ -258,10 +270,14 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
     double log_os[NS];
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
-        log_os[d] = gc.log_os[d];
+        log_os[d] = gc.k_log_os[d];
         asm volatile("" : "+v"(log_os[d]));
     }
-    const lds_f64* etab = (const lds_f64*)lds.etab;
+    // a NaN query point must give NaN rows (the status word reports it downstream): its thread reads the NaN table
+    bool znan = false;
+#pragma unroll
+    for (int j = 0; j < D; ++j) znan = znan || (z[j] != z[j]);
+    const lds_f64* etab = (const lds_f64*)lds.etab + (znan ? 128 : 0);
 
     // M = 1 or 2 training points of this thread at once: M NS independent exp chains in flight
     auto eval = [&](auto mtag, const lds_f64* x0, const lds_f64* x1, lds_f64* f0, lds_f64* f1) {
@@ -278,9 +294,9 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
             }
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
-                double a = log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2)
+                double a = log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2), in units of ln 2 / 128
 #pragma unroll
-                for (int j = 0; j < D; ++j) a = fma(sq[j], gc.nh_ils2[d * D + j], a);
+                for (int j = 0; j < D; ++j) a = fma(sq[j], gc.k_nh_ils2[d * D + j], a);
                 arg[h * NS + d] = a;
             }
         }

@@ -155,8 +155,10 @@ static GpConst<NS, NS + NU> make_gp_const(const sx_gp_model* m, int nw) {
         for (int j = 0; j < D; ++j) {
             gc.inv_ls2[d * D + j] = m->inv_ls2[d * D + j];
             gc.nh_ils2[d * D + j] = -0.5 * m->inv_ls2[d * D + j];
+            gc.k_nh_ils2[d * D + j] = gc.nh_ils2[d * D + j] * sx::kExpScale;
         }
         gc.log_os[d] = std::log(m->outputscale[d]);
+        gc.k_log_os[d] = gc.log_os[d] * sx::kExpScale;
         gc.outputscale[d] = m->outputscale[d];
         gc.noise[d] = m->noise[d];
     }

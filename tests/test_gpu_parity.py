@@ -223,3 +223,20 @@ def test_full_solve_vs_oracle():
     assert (ref_best is not None) == bool(ok[0])
     assert ref_best is not None, 'test problem should be feasible'
     np.testing.assert_allclose(best[0].cpu().numpy(), ref_best, rtol=0, atol=1e-9)
+
+
+def test_gp_predict_far_from_the_data_and_nan_queries():
+    """The table-driven exp of the Kstar phase: far away from every training point the posterior is the prior (the
+    exponent underflows, however large the distance), and a NaN query gives NaN, never a silent number."""
+    ssm, gp, env, prob = pendulum_problem(N=130)
+    s_plus_noise = np.asarray(gp.s) + np.asarray(gp.noise)
+    for far in (30.0, 1e3, 1e6, 1e12, 1e100):
+        z = np.array([[far, -far, 0.5 * far], [-far, far, far]])
+        mean, var, jac = ssm.predict_with_jacobians(T(z[:, :2]), T(z[:, 2:]))
+        assert float(mean.abs().max()) < 1e-200 and float(jac.abs().max()) < 1e-200, far
+        np.testing.assert_allclose(var.cpu().numpy(), np.broadcast_to(s_plus_noise, (2, 2)), rtol=1e-14)
+    z = np.array([[0.1, np.nan, 0.0], [0.1, 0.2, 0.0]])
+    mean, var, _ = ssm.predict_with_jacobians(T(z[:, :2]), T(z[:, 2:]))
+    assert bool(torch.isnan(mean[0]).all()) and bool(torch.isnan(var[0]).all())
+    mo, vo, _ = gp.predict(z[1:])
+    np.testing.assert_allclose(mean[1:].cpu().numpy(), mo, rtol=1e-9, atol=1e-12)   # its tile neighbour is untouched

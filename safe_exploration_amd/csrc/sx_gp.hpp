@@ -40,53 +40,86 @@ __device__ __forceinline__ int frag_index(int c, int k) {
     return (((k >> 3) * 64 + ((k & 3) << 4) + c) << 1) + ((k >> 2) & 1);
 }
 
-// 2^(j/128), j = 0..127, correctly rounded (generated with mpmath at 200 bits).
-__device__ const double kExp2Tab[128] = {
-    1.0, 1.0054299011128027, 1.0108892860517005, 1.016378314910953,
-    1.0218971486541166, 1.0274459491187637, 1.0330248790212284, 1.0386341019613787,
-    1.0442737824274138, 1.0499440858006872, 1.0556451783605572, 1.061377227289262,
-    1.0671404006768237, 1.0729348675259756, 1.0787607977571199, 1.0846183622133092,
-    1.0905077326652577, 1.0964290818163769, 1.102382583307841, 1.1083684117236787,
-    1.1143867425958924, 1.1204377524096067, 1.1265216186082418, 1.1326385195987192,
-    1.1387886347566916, 1.1449721444318042, 1.1511892299529827, 1.1574400736337511,
-    1.1637248587775775, 1.1700437696832502, 1.1763969916502812, 1.182784710984341,
-    1.189207115002721, 1.1956643920398273, 1.202156731452703, 1.2086843236265816,
-    1.215247359980469, 1.2218460329727576, 1.22848053610687, 1.2351510639369334,
-    1.241857812073484, 1.2486009771892048, 1.255380757024691, 1.2621973503942507,
-    1.2690509571917332, 1.275941778396392, 1.2828700160787783, 1.2898358734066657,
-    1.2968395546510096, 1.3038812651919358, 1.3109612115247644, 1.318079601266064,
-    1.3252366431597413, 1.3324325470831615, 1.339667524053303, 1.3469417862329458,
-    1.3542555469368927, 1.3616090206382248, 1.3690024229745905, 1.3764359707545302,
-    1.383909881963832, 1.3914243757719262, 1.3989796725383112, 1.4065759938190154,
-    1.4142135623730951, 1.4218926021691656, 1.42961333839197, 1.4373759974489824,
-    1.4451808069770467, 1.4530279958490526, 1.460917794180647, 1.4688504333369818,
-    1.4768261459394993, 1.4848451658727524, 1.4929077282912648, 1.5010140696264256,
-    1.5091644275934228, 1.5173590411982147, 1.5255981507445384, 1.533881997840956,
-    1.5422108254079407, 1.550584877685, 1.559004400237837, 1.567469639965553,
-    1.5759808451078865, 1.5845382652524937, 1.593142151342267, 1.6017927556826934,
-    1.6104903319492543, 1.6192351351948637, 1.6280274218573478, 1.6368674497669644,
-    1.645755478153965, 1.6546917676561943, 1.6636765803267364, 1.6727101796415966,
-    1.681792830507429, 1.6909247992693053, 1.7001063537185235, 1.709337763100463,
-    1.718619298122478, 1.7279512309618377, 1.7373338352737062, 1.746767386199169,
-    1.7562521603732995, 1.7657884359332727, 1.7753764925265212, 1.785016611318935,
-    1.7947090750031072, 1.804454167806624, 1.8142521755003989, 1.8241033854070534,
-    1.8340080864093424, 1.843966568958626, 1.8539791250833855, 1.864046048397789,
-    1.8741676341103, 1.8843441790323345, 1.8945759815869656, 1.9048633418176741,
-    1.9152065613971474, 1.925605943636125, 1.9360617934922943, 1.9465744175792332,
-    1.9571441241754002, 1.9677712232331759, 1.978456026387951, 1.9891988469672663,
+// 2^(j/256), j = 0..255, correctly rounded (generated with mpmath at 200 bits).
+constexpr int kExpTab = 256;
+__device__ const double kExp2Tab[kExpTab] = {
+    1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175,
+    1.0108892860517005, 1.0136300849514894, 1.016378314910953, 1.019133996077738,
+    1.0218971486541166, 1.0246677928971357, 1.0274459491187637, 1.030231637686041,
+    1.0330248790212284, 1.0358256936019572, 1.0386341019613787, 1.041450124688316,
+    1.0442737824274138, 1.0471050958792898, 1.0499440858006872, 1.0527907730046264,
+    1.0556451783605572, 1.0585073227945128, 1.061377227289262, 1.0642549128844645,
+    1.0671404006768237, 1.0700337118202419, 1.0729348675259756, 1.075843889062791,
+    1.0787607977571199, 1.0816856149932152, 1.0846183622133092, 1.0875590609177697,
+    1.0905077326652577, 1.0934643990728858, 1.0964290818163769, 1.099401802630222,
+    1.102382583307841, 1.1053714457017412, 1.1083684117236787, 1.1113735033448175,
+    1.1143867425958924, 1.1174081515673693, 1.1204377524096067, 1.12347556733302,
+    1.1265216186082418, 1.129575928566288, 1.1326385195987192, 1.1357094141578055,
+    1.1387886347566916, 1.1418762039695616, 1.1449721444318042, 1.148076478840179,
+    1.1511892299529827, 1.154310420590216, 1.1574400736337511, 1.1605782120274988,
+    1.1637248587775775, 1.1668800369524817, 1.1700437696832502, 1.1732160801636373,
+    1.1763969916502812, 1.1795865274628758, 1.182784710984341, 1.1859915656609938,
+    1.189207115002721, 1.1924313825831512, 1.1956643920398273, 1.1989061670743806,
+    1.202156731452703, 1.2054161090051239, 1.2086843236265816, 1.2119613992768012,
+    1.215247359980469, 1.2185422298274085, 1.2218460329727576, 1.2251587936371455,
+    1.22848053610687, 1.2318112847340759, 1.2351510639369334, 1.2384998981998165,
+    1.241857812073484, 1.245224830175258, 1.2486009771892048, 1.2519862778663162,
+    1.255380757024691, 1.2587844395497165, 1.2621973503942507, 1.2656195145788063,
+    1.2690509571917332, 1.2724917033894028, 1.275941778396392, 1.2794012075056693,
+    1.2828700160787783, 1.2863482295460256, 1.2898358734066657, 1.2933329732290895,
+    1.2968395546510096, 1.3003556433796506, 1.3038812651919358, 1.3074164459346773,
+    1.3109612115247644, 1.3145155879493546, 1.318079601266064, 1.3216532776031575,
+    1.3252366431597413, 1.3288297242059544, 1.3324325470831615, 1.3360451382041458,
+    1.339667524053303, 1.3432997311868353, 1.3469417862329458, 1.3505937158920345,
+    1.3542555469368927, 1.3579273062129011, 1.3616090206382248, 1.365300717204012,
+    1.3690024229745905, 1.3727141650876684, 1.3764359707545302, 1.380167867260238,
+    1.383909881963832, 1.387662042298529, 1.3914243757719262, 1.3951969099662003,
+    1.3989796725383112, 1.4027726912202048, 1.4065759938190154, 1.4103896082172707,
+    1.4142135623730951, 1.4180478843204152, 1.4218926021691656, 1.4257477441054942,
+    1.42961333839197, 1.433489413367789, 1.4373759974489824, 1.4412731191286257,
+    1.4451808069770467, 1.449099089642035, 1.4530279958490526, 1.4569675544014438,
+    1.460917794180647, 1.4648787441464057, 1.4688504333369818, 1.4728328908693675,
+    1.4768261459394993, 1.4808302278224719, 1.4848451658727524, 1.488870989524397,
+    1.4929077282912648, 1.4969554117672355, 1.5010140696264256, 1.5050837316234065,
+    1.5091644275934228, 1.5132561874526098, 1.5173590411982147, 1.5214730189088146,
+    1.5255981507445384, 1.529734466947287, 1.533881997840956, 1.5380407738316568,
+    1.5422108254079407, 1.5463921831410214, 1.550584877685, 1.5547889397770887,
+    1.559004400237837, 1.5632312899713576, 1.567469639965553, 1.5717194812923414,
+    1.5759808451078865, 1.5802537626528246, 1.5845382652524937, 1.588834384317164,
+    1.593142151342267, 1.597461597908627, 1.6017927556826934, 1.606135656416771,
+    1.6104903319492543, 1.6148568142048607, 1.6192351351948637, 1.6236253270173289,
+    1.6280274218573478, 1.632441451987275, 1.6368674497669644, 1.6413054476440063,
+    1.645755478153965, 1.6502175739206177, 1.6546917676561943, 1.6591780921616162,
+    1.6636765803267364, 1.6681872651305825, 1.6727101796415966, 1.6772453570178785,
+    1.681792830507429, 1.6863526334483934, 1.6909247992693053, 1.6955093614893326,
+    1.7001063537185235, 1.7047158096580513, 1.709337763100463, 1.713972247929926,
+    1.718619298122478, 1.723278947746274, 1.7279512309618377, 1.732636182022311,
+    1.7373338352737062, 1.7420442251551564, 1.746767386199169, 1.7515033530318782,
+    1.7562521603732995, 1.761013843037584, 1.7657884359332727, 1.7705759740635547,
+    1.7753764925265212, 1.7801900265154245, 1.785016611318935, 1.789856282321401,
+    1.7947090750031072, 1.7995750249405351, 1.804454167806624, 1.809346539371032,
+    1.8142521755003989, 1.8191711121586085, 1.8241033854070534, 1.8290490314048973,
+    1.8340080864093424, 1.8389805867758937, 1.843966568958626, 1.8489660695104508,
+    1.8539791250833855, 1.8590057724288205, 1.864046048397789, 1.8690999899412386,
+    1.8741676341103, 1.8792490180565602, 1.8843441790323345, 1.8894531543909392,
+    1.8945759815869656, 1.8997126981765553, 1.9048633418176741, 1.9100279502703899,
+    1.9152065613971474, 1.9203992131630474, 1.925605943636125, 1.930826790987627,
+    1.9360617934922943, 1.9413109895286405, 1.9465744175792332, 1.9518521162309783,
+    1.9571441241754002, 1.9624504802089273, 1.9677712232331759, 1.9731063922552343,
+    1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402,
 };
 
-constexpr double kExpScale = 128.0 / 0.693147180559945309417232;   // 128 / ln 2
-constexpr double kExpUnit = 0.693147180559945309417232 / 128.0;    // ln 2 / 128
+constexpr double kExpScale = 256.0 / 0.693147180559945309417232;   // 256 / ln 2
+constexpr double kExpUnit = 0.693147180559945309417232 / 256.0;    // ln 2 / 256
 
-// e^x for M arguments at once, table-driven; the caller passes y = x * 128 / ln 2 (it folds the factor into the
-// constants that produce x).  y = 128 n + j + f, |f| <= 1/2, so e^x = 2^n T[j] e^r with r = f ln2/128, |r| <= ln2/256:
-// T from LDS (`tab`, 128 doubles), e^r - 1 by a degree-5 polynomial.  15 VALU instructions and one LDS read per value
-// against 19 for the polynomial-only form below; error <= ~1 ulp on top of the rounding of y itself (|x| 2e-16, the
-// same as rounding x would cost).  Below e^-800 the result is 0 whatever the argument (also -inf, also 1e300
-// lengthscales away): the clamp keeps the reduction exact for every input.  A NaN argument does NOT give NaN (max
-// drops it): callers that must propagate NaN pass a table of NaNs (gp_kstar_phase does).  The M chains advance in
-// lock-step for the reason given below.
+// e^x for M arguments at once, table-driven; the caller passes y = x * 256 / ln 2 (it folds the factor into the
+// constants that produce x).  y = 256 n + j + f, |f| <= 1/2, so e^x = 2^n T[j] e^r with r = f ln2/256, |r| <= ln2/512:
+// T from LDS (`tab`, 256 doubles), e^r - 1 by a degree-4 polynomial (truncation 4e-17).  14 VALU instructions and one
+// LDS read per value against 19 for the polynomial-only form below; error <= ~1 ulp on top of the rounding of y itself
+// (|x| 2e-16, the same as rounding x would cost).  Below e^-800 the result is 0 whatever the argument (also -inf, also
+// 1e300 lengthscales away): the clamp keeps the reduction exact for every input.  A NaN argument does NOT give NaN
+// (max drops it): callers that must propagate NaN pass a table of NaNs (gp_kstar_phase does).  The M chains advance
+// in lock-step for the reason given below.
 template <int M>
 __device__ __forceinline__ void exp_tab_f64_n(const double (&y)[M], double (&out)[M],
                                               const __attribute__((address_space(3))) double* tab) {
@@ -99,13 +132,11 @@ __device__ __forceinline__ void exp_tab_f64_n(const double (&y)[M], double (&out
 #pragma unroll
     for (int i = 0; i < M; ++i) asm("v_cvt_i32_f64 %0, %1" : "=v"(mi[i]) : "v"(m[i]));
 #pragma unroll
-    for (int i = 0; i < M; ++i) t[i] = tab[mi[i] & 127];
+    for (int i = 0; i < M; ++i) t[i] = tab[mi[i] & (kExpTab - 1)];
 #pragma unroll
     for (int i = 0; i < M; ++i) r[i] = (yc[i] - m[i]) * kExpUnit;   // the difference is exact
 #pragma unroll
-    for (int i = 0; i < M; ++i) p[i] = fma(r[i], 8.33333333333333333333e-03, 4.16666666666666666667e-02);
-#pragma unroll
-    for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 1.66666666666666666667e-01);
+    for (int i = 0; i < M; ++i) p[i] = fma(r[i], 4.16666666666666666667e-02, 1.66666666666666666667e-01);
 #pragma unroll
     for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 0.5);
 #pragma unroll
@@ -113,7 +144,7 @@ __device__ __forceinline__ void exp_tab_f64_n(const double (&y)[M], double (&out
 #pragma unroll
     for (int i = 0; i < M; ++i) p[i] = p[i] * r[i];
 #pragma unroll
-    for (int i = 0; i < M; ++i) out[i] = ldexp(fma(t[i], p[i], t[i]), mi[i] >> 7);
+    for (int i = 0; i < M; ++i) out[i] = ldexp(fma(t[i], p[i], t[i]), mi[i] >> 8);
 }
 
 // e^x for M finite arguments at once (here x <= ln(outputscale)): round-to-nearest range reduction x = n ln2 + r,
@@ -153,8 +184,8 @@ struct GpConst {
     double inv_ls2[NS * D];
     double nh_ils2[NS * D];   // -1 / (2 l^2)
     double log_os[NS];        // ln(outputscale)
-    double k_nh_ils2[NS * D];  // the same two, times 128 / ln 2: the fused Kstar phase computes the exponent in units of
-    double k_log_os[NS];       // ln 2 / 128 (exp_tab_f64_n)
+    double k_nh_ils2[NS * D];  // the same two, times 256 / ln 2: the fused Kstar phase computes the exponent in units of
+    double k_log_os[NS];       // ln 2 / 256 (exp_tab_f64_n)
     double outputscale[NS];
     double noise[NS];
     const double* x_train;
@@ -173,7 +204,7 @@ struct GpTileLds {
     double* mj;     // [NS][16 rows][16]  mean / Jacobian rows
     double* part;   // [NW][NS][16]       per-wave partial sums of squares
     double* zs;     // [16][D]            query points
-    double* etab;   // [256]              2^(j/128) for exp_tab_f64_n, then 128 NaNs (the table of a NaN query point)
+    double* etab;   // [512]              2^(j/256) for exp_tab_f64_n, then 256 NaNs (the table of a NaN query point)
     __device__ double* carve(double* base, int n_train, int n_pad, int nw) {
         xs = base;
         kfrag = xs + ((n_pad * D + 1) & ~1);
@@ -181,7 +212,7 @@ struct GpTileLds {
         part = mj + NS * 256;
         zs = part + (size_t)nw * NS * 16;
         etab = zs + 16 * D;
-        return etab + 256;
+        return etab + 2 * kExpTab;
     }
 };
 
@@ -225,15 +256,15 @@ inline int gp_stage_cap(int ns, int n_pad, int nw) {
 inline int64_t gp_stage_tab_ints(int ns, int n_pad, int nw) { return 4 * (int64_t)nw * (1 + gp_stage_cap(ns, n_pad, nw)); }
 
 inline size_t gp_tile_lds_doubles(int ns, int d, int n_train, int n_pad, int nw) {
-    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d + 256;
+    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d + 2 * kExpTab;
 }
 
 template <int NS, int D>
 __device__ __forceinline__ void gp_load_xs(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds) {
     for (int i = threadIdx.x; i < gc.n_pad * D; i += blockDim.x) lds.xs[i] = i < gc.n_train * D ? gc.x_train[i] : 0.0;
-    if (threadIdx.x < 128) {
+    if (threadIdx.x < kExpTab) {
         lds.etab[threadIdx.x] = kExp2Tab[threadIdx.x];
-        lds.etab[128 + threadIdx.x] = __builtin_nan("");
+        lds.etab[kExpTab + threadIdx.x] = __builtin_nan("");
     }
 }
 
@@ -277,7 +308,7 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
     bool znan = false;
 #pragma unroll
     for (int j = 0; j < D; ++j) znan = znan || (z[j] != z[j]);
-    const lds_f64* etab = (const lds_f64*)lds.etab + (znan ? 128 : 0);
+    const lds_f64* etab = (const lds_f64*)lds.etab + (znan ? kExpTab : 0);
 
     // M = 1 or 2 training points of this thread at once: M NS independent exp chains in flight
     auto eval = [&](auto mtag, const lds_f64* x0, const lds_f64* x1, lds_f64* f0, lds_f64* f1) {
@@ -294,7 +325,7 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
             }
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
-                double a = log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2), in units of ln 2 / 128
+                double a = log_os[d];  // s_d exp(-q/2) = exp(ln s_d - q/2), in units of ln 2 / 256
 #pragma unroll
                 for (int j = 0; j < D; ++j) a = fma(sq[j], gc.k_nh_ils2[d * D + j], a);
                 arg[h * NS + d] = a;

@@ -551,8 +551,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
                 s = fma(acc[3], acc[3], fma(acc[2], acc[2], fma(acc[1], acc[1], acc[0] * acc[0])));
             }
 #pragma unroll
-            for (int dd = 0; dd < NS; ++dd)
-                if (d == dd) ssq[dd] += s;  // d is scalar: a branch, not a select
+            for (int dd = 0; dd < NS; ++dd) ssq[dd] = fma(s, (d == dd) ? 1.0 : 0.0, ssq[dd]);  // d is scalar: no branch
             acc = v4d{0.0, 0.0, 0.0, 0.0};
         }
     };

@@ -42,13 +42,22 @@ struct BlockedFitArgs {
 
 // global (row-major, leading dimension n) block (bi, bj) -> LDS [64][kFLd]; outside the matrix: zero, or the identity
 // when `unit_pad` (so that a padded diagonal block stays positive definite / invertible)
+// (all 16 loads of a thread are issued before the first store: one memory round trip per block, not sixteen)
 __device__ __forceinline__ void load_block(double* dst, const double* M, int n, int bi, int bj, bool unit_pad) {
-    for (int idx = threadIdx.x; idx < kFB * kFB; idx += kFThreads) {
+    constexpr int kPer = kFB * kFB / kFThreads;
+    double v[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int idx = threadIdx.x + u * kFThreads;
         const int r = idx >> 6, c = idx & 63;
         const int gr = bi * kFB + r, gc = bj * kFB + c;
-        double v = (unit_pad && r == c) ? 1.0 : 0.0;
-        if (gr < n && gc < n) v = M[(size_t)gr * n + gc];
-        dst[r * kFLd + c] = v;
+        v[u] = (unit_pad && r == c) ? 1.0 : 0.0;
+        if (gr < n && gc < n) v[u] = M[(size_t)gr * n + gc];
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int idx = threadIdx.x + u * kFThreads;
+        dst[(idx >> 6) * kFLd + (idx & 63)] = v[u];
     }
 }
 
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(kFThreads) void fit_potrf_diag_kernel(BlockedFitArg
         if (tid >= j && tid < kFB) L[tid * kFLd + j] = (tid == j) ? piv : L[tid * kFLd + j] / piv;
         __syncthreads();
         // rank-1 update of the trailing lower triangle: rows r > j, columns j < c <= r
-        for (int idx = tid; idx < kFB * kFB; idx += kFThreads) {
+        for (int idx = ((j + 1) << 6) + tid; idx < kFB * kFB; idx += kFThreads) {
             const int r = idx >> 6, c = idx & 63;
             if (c > j && c <= r) L[r * kFLd + c] -= L[r * kFLd + j] * L[c * kFLd + j];
         }
@@ -188,32 +197,64 @@ __global__ __launch_bounds__(kFThreads) void fit_syrk_kernel(BlockedFitArgs fa, 
     });
 }
 
-// block column j of W: W_jj is in place; W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj for i > j
+// block column j of W: W_jj is in place; W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj for i > j.  The 64 columns of a block
+// column are independent, so a workgroup takes a strip of 16 of them (blockIdx.z): four times the workgroups, a
+// quarter of the serial chain each.
+__device__ __forceinline__ void load_strip(double* dst, const double* M, int n, int bi, int bj, int strip) {
+    // columns 16 strip .. 16 strip + 15 of block (bi, bj) -> dst[64][kFLd] (same column positions)
+    constexpr int kPer = kFB * 16 / kFThreads;
+    double v[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int idx = threadIdx.x + u * kFThreads;
+        const int r = idx >> 4, c = 16 * strip + (idx & 15);
+        const int gr = bi * kFB + r, gc = bj * kFB + c;
+        v[u] = (gr < n && gc < n) ? M[(size_t)gr * n + gc] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int idx = threadIdx.x + u * kFThreads;
+        dst[(idx >> 4) * kFLd + 16 * strip + (idx & 15)] = v[u];
+    }
+}
+
+// acc += A[16 w .. 16 w + 15][0..63] . B[0..63][16 strip .. 16 strip + 15]   (NN)
+__device__ __forceinline__ void strip_mma(v4d& acc, const double* As, const double* Bs, int strip) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* arow = As + (16 * wave + (lane & 15)) * kFLd + (lane >> 4);
+    const double* bcol = Bs + (lane >> 4) * kFLd + 16 * strip + (lane & 15);
+#pragma unroll 4
+    for (int k0 = 0; k0 < kFB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[k0], bcol[k0 * kFLd], acc, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(kFThreads) void fit_trtri_kernel(BlockedFitArgs fa) {
     __shared__ double As[kFB * kFLd];
     __shared__ double Bs[kFB * kFLd];
-    const int d = blockIdx.y, j = blockIdx.x, n = fa.n;
+    const int d = blockIdx.y, j = blockIdx.x, strip = blockIdx.z, n = fa.n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* A = fa.lmat + (size_t)d * n * n;
     double* W = fa.linv + (size_t)d * n * n;
     for (int i = j + 1; i < fa.nblk; ++i) {
-        v4d acc[4] = {};
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
         for (int k = j; k < i; ++k) {
             __syncthreads();  // the previous product has been read out of LDS (and W_kj of the previous i is written)
             load_block(As, A, n, i, k, false);
-            load_block(Bs, W, n, k, j, false);
+            load_strip(Bs, W, n, k, j, strip);
             __syncthreads();
-            block_mma<false>(acc, As, Bs);
+            strip_mma(acc, As, Bs, strip);
         }
         __syncthreads();
         load_block(As, W, n, i, i, false);
-        for_each_result(acc, [&](int r, int c, double v) { Bs[r * kFLd + c] = v; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Bs[(16 * wave + (lane >> 4) + 4 * r) * kFLd + 16 * strip + (lane & 15)] = acc[r];
         __syncthreads();
-        v4d out[4] = {};
-        block_mma<false>(out, As, Bs);
-        for_each_result(out, [&](int r, int c, double v) {
-            const int gr = i * kFB + r, gc = j * kFB + c;
-            if (gr < n && gc < n) W[(size_t)gr * n + gc] = -v;
-        });
+        v4d out = {0.0, 0.0, 0.0, 0.0};
+        strip_mma(out, As, Bs, strip);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = i * kFB + 16 * wave + (lane >> 4) + 4 * r, gc = j * kFB + 16 * strip + (lane & 15);
+            if (gr < n && gc < n) W[(size_t)gr * n + gc] = -out[r];
+        }
         __threadfence_block();
     }
 }

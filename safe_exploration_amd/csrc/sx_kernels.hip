@@ -485,7 +485,7 @@ int sx_gp_fit(const sx_gp_model* model, const double* y_train, double* work, dou
                 hipLaunchKernelGGL(sx::fit_syrk_kernel, dim3(m, m, ns), dim3(sx::kFThreads), 0, s, ba, p);
             }
         }
-        hipLaunchKernelGGL(sx::fit_trtri_kernel, dim3(nb, ns), dim3(sx::kFThreads), 0, s, ba);
+        hipLaunchKernelGGL(sx::fit_trtri_kernel, dim3(nb, ns, sx::kFB / 16), dim3(sx::kFThreads), 0, s, ba);
         hipLaunchKernelGGL(sx::fit_alpha_logdet_kernel, dim3(ns), dim3(1024), sizeof(double) * (size_t)ba.n, s, ba);
         return sx::check_launch();
     }

@@ -72,12 +72,14 @@ def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, act
 
 def cem_rank_refit(con: Tensor, obj: Tensor, actions: Tensor, k: int, *, cost_stride: int = 1,
                    act_stride: Optional[int] = None, row_len: Optional[int] = None, num_candidates: Optional[int] = None,
-                   num_problems: Optional[int] = None, want_rows: bool = False, want_refit: bool = True):
+                   num_problems: Optional[int] = None, want_rows: bool = False, want_refit: bool = True,
+                   rows_out: Optional[Tensor] = None):
     """Thin wrapper over sx_cem_rank_refit for E problems.
 
     Plain layout: con/obj [E x P], actions [E x P x ...].  Candidate-row layout (after the multi-GPU exchange): pass
     views into a [E x C x (2 + L)] buffer with cost_stride = act_stride = 2 + L, row_len = L, num_candidates = C,
-    num_problems = E.
+    num_problems = E.  `rows_out` (contiguous [E x k x (2 + L)]) receives the elite rows in place of a fresh tensor: the
+    multi-GPU solve hands in this rank's slot of the exchange buffer.
     """
     dev = con.device
     E = num_problems if num_problems is not None else con.size(0)
@@ -85,7 +87,13 @@ def cem_rank_refit(con: Tensor, obj: Tensor, actions: Tensor, k: int, *, cost_st
     L = row_len if row_len is not None else actions[0, 0].numel()
     act_stride = act_stride if act_stride is not None else L
     idx = torch.empty((E, k), dtype=torch.int32, device=dev)
-    rows = torch.empty((E, k, 2 + L), dtype=torch.float64, device=dev) if want_rows else None
+    rows = None
+    if rows_out is not None:
+        if tuple(rows_out.shape) != (E, k, 2 + L) or not rows_out.is_contiguous() or rows_out.dtype != torch.float64:
+            raise ValueError(f'rows_out must be a contiguous float64 [{E} x {k} x {2 + L}] tensor')
+        rows = rows_out
+    elif want_rows:
+        rows = torch.empty((E, k, 2 + L), dtype=torch.float64, device=dev)
     mean = torch.empty((E, L), dtype=torch.float64, device=dev) if want_refit else None
     std = torch.empty((E, L), dtype=torch.float64, device=dev) if want_refit else None
     best = torch.empty((E, L), dtype=torch.float64, device=dev)
@@ -164,6 +172,7 @@ class FusedCemMpc:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         history: List[Rollouts] = []
         out = None
+        xbuf = None
         if noise is None and 'sample_noise' not in vars(self):
             # one generator launch for the whole solve instead of one per iteration (a test that patches sample_noise
             # on the instance still gets its per-iteration calls)
@@ -190,8 +199,17 @@ class FusedCemMpc:
                 out = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites)
             else:
                 k = self._local_elites
-                local = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_rows=True, want_refit=False)
-                cand = distributed.exchange_elite_rows(local['elite_rows'], self._group)   # [E x G*k x (2 + L)]
+                if xbuf is None:
+                    # the zero-padded exchange buffers of ALL iterations in one allocation (one memset per solve)
+                    xbuf = torch.zeros((self._num_iterations, E, self._world, k, 2 + L), dtype=torch.float64, device=dev)
+                if E == 1:
+                    # the local elite rows go straight into this rank's slot: no copy between the kernel and the collective
+                    cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_refit=False,
+                                   rows_out=xbuf[it, :, self._rank])
+                else:
+                    local = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_rows=True, want_refit=False)
+                    xbuf[it, :, self._rank] = local['elite_rows']
+                cand = distributed.all_reduce_slots(xbuf[it], self._group)                   # [E x G*k x (2 + L)]
                 flat = cand.view(-1)
                 out = cem_rank_refit(flat, flat[1:], flat[2:], self._num_elites, cost_stride=2 + L,
                                      act_stride=2 + L, row_len=L, num_candidates=cand.size(1), num_problems=E)

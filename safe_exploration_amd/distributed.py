@@ -46,5 +46,13 @@ def exchange_elite_rows(rows: Tensor, group=None) -> Tensor:
     return buf.view(E, world * k, W)
 
 
+def all_reduce_slots(buf: Tensor, group=None) -> Tensor:
+    """buf [E x G x k x W], zero everywhere but in this rank's slot [:, rank] -> the same buffer after ONE
+    all-reduce(sum), viewed [E x G*k x W] (what exchange_elite_rows returns, without its allocation and copy)."""
+    E, world, k, W = buf.shape
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf.view(E, world * k, W)
+
+
 def all_reduce_max_(t: Tensor, group=None) -> None:
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)

@@ -35,6 +35,12 @@ def _worker(rank, port, P, k, L, out):
         cand = distributed.exchange_elite_rows(torch.tensor(rows[None]), dist.group.WORLD)[0].numpy()
         assert cand.shape == (WORLD * k, 2 + L)
         np.testing.assert_array_equal(cand[rank * k:(rank + 1) * k], rows)         # own slot untouched
+        # the form the solver uses: the rows are written straight into this rank's slot of a zeroed buffer
+        buf = torch.zeros((1, WORLD, k, 2 + L), dtype=torch.float64)
+        buf[0, rank] = torch.tensor(rows)
+        cand2 = distributed.all_reduce_slots(buf, dist.group.WORLD)
+        assert cand2.data_ptr() == buf.data_ptr()                                   # in place, no copy
+        np.testing.assert_array_equal(cand2[0].numpy(), cand)
         # global selection from the candidates == selection from the whole population
         sel = ocem.rank(cand[:, 0], cand[:, 1], k)
         want = ocem.rank(con, obj, k)

@@ -87,7 +87,7 @@ def main():
     import torch.distributed as dist
 
     from safe_exploration_amd import problems
-    from safe_exploration_amd.cem_mpc import FusedCemMpc
+    from safe_exploration_amd.cem_mpc import FusedCemMpc, fold_status
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -132,7 +132,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
-    status_word = int(status.item())
+    status_word = fold_status(status.cpu())
     rollout_ms = [a.elapsed_time(b) for a, b in mpc.rollout_events]
     mpc.rollout_events = None
     avg_rollout_s = sum(rollout_ms) / len(rollout_ms) * 1e-3

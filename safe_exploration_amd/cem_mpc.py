@@ -105,6 +105,14 @@ def cem_rank_refit(con: Tensor, obj: Tensor, actions: Tensor, k: int, *, cost_st
     return dict(elite_idx=idx, elite_rows=rows, mean=mean, std=std, best=best, best_ok=best_ok)
 
 
+def fold_status(words) -> int:
+    """Bitwise OR of the per-rank status words `solve` returns (host side: a handful of ints)."""
+    out = 0
+    for w in words.reshape(-1).tolist():
+        out |= int(w)
+    return out
+
+
 class FusedCemMpc:
     """Drop-in for ``ConstrainedCemMpc``: ``get_actions(flat_state [1 x S]) -> (actions [H x n_u] | None, rollouts)``.
 
@@ -159,7 +167,8 @@ class FusedCemMpc:
         """E independent solves from x0 [E x n_s] (points).  Nothing here synchronises with the host.
 
         noise: optional [iters x E x P_local x H x n_u] pre-drawn standard normals (parity tests inject them).
-        Returns (best [E x H x n_u], best_ok int32 [E], rollouts per iteration (if recorded), status int32 [1]).
+        Returns (best [E x H x n_u], best_ok int32 [E], rollouts per iteration (if recorded), status int32 [G]: the
+        status word of every rank, identical on all ranks; G = 1 without a process group -- OR them, `fold_status`).
         """
         n_u, H = self._ssm.num_actions, self._horizon
         E = x0.size(0)
@@ -199,27 +208,33 @@ class FusedCemMpc:
                 out = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites)
             else:
                 k = self._local_elites
+                G, n_slots = self._world, E * self._world * k * (2 + L)
                 if xbuf is None:
-                    # the zero-padded exchange buffers of ALL iterations in one allocation (one memset per solve)
-                    xbuf = torch.zeros((self._num_iterations, E, self._world, k, 2 + L), dtype=torch.float64, device=dev)
+                    # the zero-padded exchange buffers of ALL iterations in one allocation (one memset per solve); each
+                    # carries G extra cells behind the slots: the status words ride along with the last exchange
+                    xbuf = torch.zeros((self._num_iterations, n_slots + G), dtype=torch.float64, device=dev)
+                slots = xbuf[it, :n_slots].view(E, G, k, 2 + L)
                 if E == 1:
                     # the local elite rows go straight into this rank's slot: no copy between the kernel and the collective
                     cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_refit=False,
-                                   rows_out=xbuf[it, :, self._rank])
+                                   rows_out=slots[:, self._rank])
                 else:
                     local = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_rows=True, want_refit=False)
-                    xbuf[it, :, self._rank] = local['elite_rows']
-                cand = distributed.all_reduce_slots(xbuf[it], self._group)                   # [E x G*k x (2 + L)]
-                flat = cand.view(-1)
+                    slots[:, self._rank] = local['elite_rows']
+                last = it == self._num_iterations - 1
+                if last:
+                    xbuf[it, n_slots + self._rank] = status[0]      # every rollout of this solve has been enqueued
+                distributed.all_reduce_sum_(xbuf[it], self._group)               # the ONE collective of the iteration
+                if last:
+                    # every rank now holds the status words of all ranks: callers OR them, so all ranks raise together
+                    status = xbuf[it, n_slots:].to(torch.int32)
+                flat = slots.view(-1)
                 out = cem_rank_refit(flat, flat[1:], flat[2:], self._num_elites, cost_stride=2 + L,
-                                     act_stride=2 + L, row_len=L, num_candidates=cand.size(1), num_problems=E)
+                                     act_stride=2 + L, row_len=L, num_candidates=G * k, num_problems=E)
             mean, std = out['mean'].view(E, H, n_u), out['std'].view(E, H, n_u)
             if self._record:
                 for e in range(E):
                     history.append(Rollouts(r['traj'][e], r['actions'][e], r['obj_cost'][e], r['con_cost'][e]))
-        if self._world > 1:
-            # the status word is per rank; fold it so that every rank raises (or not) together
-            distributed.all_reduce_max_(status, self._group)
         return out['best'].view(E, H, n_u), out['best_ok'], history, status
 
     def get_actions_batch(self, states: Tensor) -> Tuple[Tensor, Tensor, List[Rollouts]]:
@@ -237,9 +252,9 @@ class FusedCemMpc:
         x0 = states[:, :n_s].to(self._device, torch.float64).contiguous()
         best, best_ok, history, status = self.solve(x0)
         flags = torch.cat((status, best_ok)).cpu()   # the one device->host hand-off of the batch
-        self.last_status = int(flags[0])
+        self.last_status = fold_status(flags[:status.numel()])
         raise_for_status(self.last_status, 'get_actions_batch')
-        return best, flags[1:] != 0, history
+        return best, flags[status.numel():] != 0, history
 
     def get_actions(self, state: Tensor) -> Tuple[Optional[Tensor], List[Rollouts]]:
         """state: the flat start state [1 x (n_s + n_s^2)] with an all-zero Q block (a point, safempc_cem.py:234-235)."""
@@ -253,8 +268,8 @@ class FusedCemMpc:
         best, best_ok, history, status = self.solve(x0)
         # the one device->host hand-off of a solve: status word + feasibility flag (+ the actions)
         flags = torch.cat((status, best_ok)).cpu()
-        self.last_status = int(flags[0])
+        self.last_status = fold_status(flags[:status.numel()])
         raise_for_status(self.last_status, 'get_actions')
-        if int(flags[1]) == 0:
+        if int(flags[status.numel()]) == 0:
             return None, history
         return best[0], history

@@ -54,5 +54,11 @@ def all_reduce_slots(buf: Tensor, group=None) -> Tensor:
     return buf.view(E, world * k, W)
 
 
+def all_reduce_sum_(buf: Tensor, group=None) -> None:
+    """In-place all-reduce(sum) of a buffer in which every rank has filled only its own cells (zeros elsewhere):
+    all-gather-shaped, and adding zeros is exact."""
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+
+
 def all_reduce_max_(t: Tensor, group=None) -> None:
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)

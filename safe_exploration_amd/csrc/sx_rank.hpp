@@ -1,6 +1,7 @@
 // Elite ranking + refit kernel (sx_cem_rank_refit).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "../../include/sx_amd.h"
 #include "sx_rollout.hpp"  // stamp() in diagnostic builds
@@ -34,14 +35,87 @@ __device__ __forceinline__ unsigned long long sortable_key(double x) {
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// inclusive prefix sum over the 64 lanes of a wave
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
+// Cross-lane moves on the DPP path of the VALU (no LDS round trip, unlike __shfl_*): row_shr:n shifts within a row of
+// 16 lanes, row_bcast:15 / :31 hand the last lane of a row / of the first half on to the following row(s).
+template <int CTRL, int ROW_MASK, bool BOUND_ZERO>
+__device__ __forceinline__ int dpp_move(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, BOUND_ZERO);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+// inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside the rows, then the row totals
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
+    v += dpp_move<kDppRowShr1, 0xf, true>(0, v);
+    v += dpp_move<kDppRowShr2, 0xf, true>(0, v);
+    v += dpp_move<kDppRowShr4, 0xf, true>(0, v);
+    v += dpp_move<kDppRowShr8, 0xf, true>(0, v);
+    v += dpp_move<kDppRowBcast15, 0xa, false>(0, v);   // rows 1 and 3 += total of the row before
+    v += dpp_move<kDppRowBcast31, 0xc, false>(0, v);   // rows 2 and 3 += total of rows 0-1
     return v;
+}
+
+// sum over each row of 16 lanes, valid in the row's last lane
+__device__ __forceinline__ double row16_sum(double v) {
+    auto shr = [](double x, auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        const long long b = __double_as_longlong(x);
+        const int lo = dpp_move<C, 0xf, true>(0, (int)(b & 0xffffffffll)), hi = dpp_move<C, 0xf, true>(0, (int)(b >> 32));
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);   // lanes without a source get +0.0
+    };
+    v += shr(v, std::integral_constant<int, kDppRowShr1>{});
+    v += shr(v, std::integral_constant<int, kDppRowShr2>{});
+    v += shr(v, std::integral_constant<int, kDppRowShr4>{});
+    v += shr(v, std::integral_constant<int, kDppRowShr8>{});
+    return v;
+}
+
+// column totals of red[R][Lc] (row-major): 16 lanes per column and a row reduction when the columns fit (Lc <= 64),
+// else one thread per column; `store(c, total)` is called once per column
+template <class Store>
+__device__ __forceinline__ void column_totals(const double* red, int Lc, int R, int tid, Store&& store) {
+    if (Lc <= 64) {
+        const int c = tid >> 4, j = tid & 15;
+        double t = 0.0;
+        if (c < Lc)
+            for (int g = j; g < R; g += 16) t += red[g * Lc + c];
+        t = row16_sum(t);
+        if (c < Lc && j == 15) store(c, t);
+    } else if (tid < Lc) {
+        double t = 0.0;
+        for (int g = 0; g < R; ++g) t += red[g * Lc + tid];
+        store(tid, t);
+    }
+}
+
+// minimum of (hi, lo, idx) triples over the wave, lexicographic; the result is valid in lane 63
+struct RankKey {
+    unsigned long long h, l;
+    int i;
+};
+__device__ __forceinline__ bool key_less(const RankKey& a, const RankKey& b) {
+    return a.h < b.h || (a.h == b.h && (a.l < b.l || (a.l == b.l && a.i < b.i)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ RankKey key_min_step(const RankKey& k) {
+    // lanes without a source (row edge, masked rows) see the key itself: the minimum is unchanged there
+    RankKey o;
+    const int hl = (int)(k.h & 0xffffffffu), hh = (int)(k.h >> 32), ll = (int)(k.l & 0xffffffffu), lh = (int)(k.l >> 32);
+    const unsigned int ohl = (unsigned int)dpp_move<CTRL, ROW_MASK, false>(hl, hl), ohh = (unsigned int)dpp_move<CTRL, ROW_MASK, false>(hh, hh);
+    const unsigned int oll = (unsigned int)dpp_move<CTRL, ROW_MASK, false>(ll, ll), olh = (unsigned int)dpp_move<CTRL, ROW_MASK, false>(lh, lh);
+    o.h = ((unsigned long long)ohh << 32) | ohl;
+    o.l = ((unsigned long long)olh << 32) | oll;
+    o.i = dpp_move<CTRL, ROW_MASK, false>(k.i, k.i);
+    return key_less(o, k) ? o : k;
+}
+__device__ __forceinline__ RankKey wave_min_key(RankKey k) {
+    k = key_min_step<kDppRowShr1, 0xf>(k);
+    k = key_min_step<kDppRowShr2, 0xf>(k);
+    k = key_min_step<kDppRowShr4, 0xf>(k);
+    k = key_min_step<kDppRowShr8, 0xf>(k);     // lane 15 of every row: the row's minimum
+    k = key_min_step<kDppRowBcast15, 0xa>(k);  // lane 31: rows 0-1, lane 63: rows 2-3
+    k = key_min_step<kDppRowBcast31, 0xc>(k);  // lane 63: the wave
+    return k;
 }
 
 struct RankArgs {
@@ -117,13 +191,10 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         // which keeps best_idx valid when every key is the NaN key)
         if (i < P && (bi == 0x7fffffff || kh[s] < bh || (kh[s] == bh && kl[s] < bl))) { bh = kh[s]; bl = kl[s]; bi = i; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long oh = __shfl_xor(bh, off), ol = __shfl_xor(bl, off);
-        const int oi = __shfl_xor(bi, off);
-        if (oh < bh || (oh == bh && (ol < bl || (ol == bl && oi < bi)))) { bh = oh; bl = ol; bi = oi; }
+    {
+        const RankKey wk = wave_min_key(RankKey{bh, bl, bi});
+        if (lane == 63) { red_h[wave] = wk.h; red_l[wave] = wk.l; red_i[wave] = wk.i; }
     }
-    if (lane == 0) { red_h[wave] = bh; red_l[wave] = bl; red_i[wave] = bi; }
     __syncthreads();  // (also publishes the cleared histograms / walk cells)
 #pragma unroll
     for (int w = 0; w < kRankWaves; ++w) {
@@ -337,11 +408,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             }
             red[tid] = s;
             __syncthreads();
-            if (tid < Lc) {
-                double t = 0.0;
-                for (int g = 0; g < R; ++g) t += red[g * Lc + tid];
-                col_mean[tid] = t / k;
-            }
+            column_totals(red, Lc, R, tid, [&](int cc, double t) { col_mean[cc] = t / k; });
             __syncthreads();
             const double mu = col_mean[c];
             double ss = 0.0;
@@ -358,12 +425,10 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             }
             red[tid] = ss;  // (the column owners finished reading red before the barrier above)
             __syncthreads();
-            if (tid < Lc) {
-                double t = 0.0;
-                for (int g = 0; g < R; ++g) t += red[g * Lc + tid];
-                ra.mean[(long long)e * L + c0 + tid] = col_mean[tid];
-                if (ra.std) ra.std[(long long)e * L + c0 + tid] = (k > 1) ? sqrt(t / (k - 1)) : 0.0;
-            }
+            column_totals(red, Lc, R, tid, [&](int cc, double t) {
+                ra.mean[(long long)e * L + c0 + cc] = col_mean[cc];
+                if (ra.std) ra.std[(long long)e * L + c0 + cc] = (k > 1) ? sqrt(t / (k - 1)) : 0.0;
+            });
             __syncthreads();
         }
     }

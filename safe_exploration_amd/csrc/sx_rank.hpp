@@ -203,6 +203,9 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         if (oh < bh || (oh == bh && (ol < bl || (ol == bl && oi < bi)))) { bh = oh; bl = ol; bi = oi; }
     }
     const int best_idx = bi;  // uniform
+#ifdef SX_STAMPS
+    const unsigned long long tsa = stamp();
+#endif
 
     // ---- the k-th key ----
     unsigned long long ph = 0, pl = 0;   // prefix of the k-th key found so far (uniform)
@@ -250,7 +253,14 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             acc += cnt;
         }
     }
+#ifdef SX_STAMPS
+    const unsigned long long tsb = stamp();
+    int npass = 0;
+#endif
     for (int pass = first_pass; pass < 16 && !done; ++pass) {
+#ifdef SX_STAMPS
+        ++npass;
+#endif
         const int shift = 56 - 8 * (pass & 7);
         const bool in_hi = pass < 8;
         unsigned int* h = hist[pass % 3];
@@ -261,6 +271,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             const int i = s * kRankThreads + tid;
             const bool match = (i < P) && ((kh[s] & mh) == ph) && ((kl[s] & ml) == pl);
             const unsigned int digit = match ? (unsigned int)(((in_hi ? kh[s] : kl[s]) >> shift) & 255ull) : 0xffffffffu;
+            // (a ballot-per-distinct-digit aggregation was measured twice: slower than the plain atomics it saves)
             const unsigned int first = __builtin_amdgcn_readfirstlane(digit);
             if (__all(digit == first)) {
                 if (first != 0xffffffffu && lane == 0) atomicAdd(&h[first], 64u);
@@ -436,6 +447,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     const unsigned long long ts4 = stamp();
     if (g_stamp_buf && tid == 0 && e == 0) {
         g_stamp_buf[0] = ts1 - ts0; g_stamp_buf[1] = ts2 - ts1; g_stamp_buf[2] = ts3 - ts2; g_stamp_buf[3] = ts4 - ts3;
+        g_stamp_buf[4] = tsa - ts0; g_stamp_buf[5] = tsb - tsa; g_stamp_buf[6] = ts1 - tsb; g_stamp_buf[7] = npass;
     }
 #endif
 }

@@ -18,4 +18,5 @@ for feas in (0.5, 0.02):
     for _ in range(3):
         cem_rank_refit(con, obj, act, k)
     torch.cuda.synchronize()
-    print(f'feasible fraction {feas}: select/compact/sort/output+refit cycles =', buf[:4].tolist())
+    print(f'feasible fraction {feas}: select/compact/sort/output+refit cycles =', buf[:4].tolist(),
+          ' select = best/walk/passes', buf[4:7].tolist(), 'in', int(buf[7]), 'radix passes')

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
 #ifdef SX_STAMPS
     const unsigned long long tsb = stamp();
     int npass = 0;
+    unsigned long long pass_t[3] = {0, 0, 0};
 #endif
     for (int pass = first_pass; pass < 16 && !done; ++pass) {
 #ifdef SX_STAMPS
@@ -279,7 +280,13 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
                 atomicAdd(&h[digit], 1u);
             }
         }
+#ifdef SX_STAMPS
+        const unsigned long long tp1 = stamp();
+#endif
         __syncthreads();
+#ifdef SX_STAMPS
+        const unsigned long long tp2 = stamp();
+#endif
         // every wave scans the 256 bins itself: lane l owns bins 4l .. 4l+3
         const unsigned int c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
         const int mine = (int)(c0 + c1 + c2 + c3);
@@ -298,6 +305,10 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         done = __builtin_amdgcn_readlane((int)(rem == (int)cnt), src) != 0;  // whole bin selected: lower digits do not matter
         const unsigned long long dg = (unsigned long long)digit_sel << shift, mk = 255ull << shift;
         if (in_hi) { ph |= dg; mh |= mk; } else { pl |= dg; ml |= mk; }
+#ifdef SX_STAMPS
+        const unsigned long long tp3 = stamp();
+        if (npass == 1) { pass_t[0] = tp1 - tsb; pass_t[1] = tp2 - tp1; pass_t[2] = tp3 - tp2; }
+#endif
     }
 #ifdef SX_STAMPS
     const unsigned long long ts1 = stamp();
@@ -448,6 +459,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     if (g_stamp_buf && tid == 0 && e == 0) {
         g_stamp_buf[0] = ts1 - ts0; g_stamp_buf[1] = ts2 - ts1; g_stamp_buf[2] = ts3 - ts2; g_stamp_buf[3] = ts4 - ts3;
         g_stamp_buf[4] = tsa - ts0; g_stamp_buf[5] = tsb - tsa; g_stamp_buf[6] = ts1 - tsb; g_stamp_buf[7] = npass;
+        g_stamp_buf[8] = pass_t[0]; g_stamp_buf[9] = pass_t[1]; g_stamp_buf[10] = pass_t[2];
     }
 #endif
 }

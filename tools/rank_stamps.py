@@ -6,7 +6,7 @@ from safe_exploration_amd import _lib
 from safe_exploration_amd.cem_mpc import cem_rank_refit
 dev = torch.device('cuda:0')
 P, k, L = int(os.environ.get('P', 4096)), int(os.environ.get('K', 409)), 15
-buf = torch.zeros(8, dtype=torch.int64, device=dev)
+buf = torch.zeros(16, dtype=torch.int64, device=dev)
 lib = _lib.lib()
 lib.sx_debug_set_stamps.argtypes = [ctypes.c_void_p]
 assert lib.sx_debug_set_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
@@ -19,4 +19,4 @@ for feas in (0.5, 0.02):
         cem_rank_refit(con, obj, act, k)
     torch.cuda.synchronize()
     print(f'feasible fraction {feas}: select/compact/sort/output+refit cycles =', buf[:4].tolist(),
-          ' select = best/walk/passes', buf[4:7].tolist(), 'in', int(buf[7]), 'radix passes')
+          ' select = best/walk/passes', buf[4:7].tolist(), 'in', int(buf[7]), 'radix passes; first pass = count/barrier/scan', buf[8:11].tolist())

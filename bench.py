@@ -141,6 +141,7 @@ def main():
         particle_steps = total_particles * H * iters * args.steps
         flops_unit = algorithmic_flops_per_particle_step(spec.n_s, args.n_train, spec.n_s + spec.n_u)
         achieved = flops_unit * P * H / avg_rollout_s / 1e12
+        traffic = pmc_traffic(f'cfg2 pendulum N_train={args.n_train} H={H} P={P}')
         out = {
             'metric': 'cem_particle_step_evals_per_s', 'value': particle_steps / elapsed, 'unit': 'particle-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -154,10 +155,12 @@ def main():
             'device_status': status_word, 'solution_found': bool(ok[0].item()),
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / F64_MATRIX_PEAK_TFLOPS,
-                         'traffic': pmc_traffic(f'cfg2 pendulum N_train={args.n_train} H={H} P={P}'),
+                         'traffic': traffic,
                          'traffic_unit': 'B/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.json)',
                          'kernel': 'cem_rollout_kernel<2,1>',
                          'avg_launch_us': avg_rollout_s * 1e6, 'launches_timed': len(rollout_ms),
+                         'hbm_gb_per_s': (traffic / avg_rollout_s / 1e9) if traffic else None,
+                         'hbm_frac_of_8TBps': (traffic / avg_rollout_s / 8e12) if traffic else None,
                          'algorithmic_flops_per_launch': flops_unit * P * H},
         }
         if world == 1 and not args.no_cpu_baseline:

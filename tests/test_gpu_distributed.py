@@ -44,7 +44,18 @@ def _worker(rank, port, out):
         ref, _ = ocem.cem_solve(problems.oracle_problem(spec, ocem), gp, x0, noise, k, init_std=np.full((H, 1), 0.2))
         assert tuple(status.shape) == (WORLD,) and not bool(status.any()) and ref is not None and int(ok[0]) == 1
         np.testing.assert_allclose(best[0].cpu().numpy(), ref, rtol=0, atol=1e-9)
-        out[rank] = best[0].cpu().numpy().tobytes()
+        # two problems at once through the same sharded path (the slot copy of the E > 1 branch)
+        x02 = np.array([[0.015, -0.02], [-0.03, 0.04]])
+        noise2 = rng.normal(size=(iters, 2, P, H, 1))
+        best2, ok2, _, status2 = mpc.solve(t(x02), noise=t(noise2[:, :, lo:hi]))
+        assert not bool(status2.any())
+        for e in range(2):
+            ref_e, _ = ocem.cem_solve(problems.oracle_problem(spec, ocem), gp, x02[e], noise2[:, e], k,
+                                      init_std=np.full((H, 1), 0.2))
+            assert (ref_e is not None) == bool(ok2[e])
+            if ref_e is not None:
+                np.testing.assert_allclose(best2[e].cpu().numpy(), ref_e, rtol=0, atol=1e-9)
+        out[rank] = best[0].cpu().numpy().tobytes() + best2.cpu().numpy().tobytes()
     finally:
         dist.destroy_process_group()
 

@@ -269,15 +269,17 @@ __device__ __forceinline__ void gp_load_xs(const GpConst<NS, D>& gc, GpTileLds<N
 }
 
 // Phase 1: Kstar_d[c][k] = s_d exp(-1/2 sum_j (z_cj - X_kj)^2 / l_dj^2) for the tile's 16 points, all k < n_pad, all d.
-// The rows are dealt out in groups of 4 to `nworkers` waves (group g -> worker g % nworkers); the calling wave is
-// `worker` and handles 16 query points x 4 rows at a time (in the rollout not every wave is a worker: wave 0 finishes
-// the previous step meanwhile).
+// The rows are dealt out in PAIRS of fragments (8 rows: k = 8 q .. 8 q + 7, n_pad / 8 of them); the calling wave
+// works off the pairs [q_begin, q_end), one pair per trip: lane (c = lane & 15, kk = lane >> 4) computes rows 8 q + kk
+// and 8 q + kk + 4, the two slots of ONE 16-byte fragment element.  Waves may own different numbers of pairs
+// (kstar_pair_range): in the rollout wave 0 finishes the previous step meanwhile and the wave that shares its SIMD
+// gets half a share.
 //
 // The phase is bound by VALU issue, on the pipe the f64 MFMAs use too (tools/overlap_probe.hip), so what counts is the
 // instruction count per value.  Columns k >= n_train of W and of the mean/Jacobian rows are zero (pack_a_kernel), so the
 // padding entries of Kstar only have to be finite: they are computed like any other from the zero rows gp_load_xs
-// appends to X -- no index clamp, no select.  A thread visits k0, k0 + kstep, k0 + 2 kstep, ... with
-// kstep = 4 nworkers, so two visits on, k & 7 is the same and both the X row and the fragment slot move by a constant.
+// appends to X -- no index clamp, no select; and from trip to trip both the X rows and the fragment element move by a
+// constant.
 // Kstar lives in LDS as [pair q = k >> 3][output d][lane = ((k & 3) << 4) + c][slot = (k >> 2) & 1]: one ds_read_b128
 // per lane feeds two MFMAs of one output, and the NS values a Kstar thread produces for one (c, k) are a constant
 // 1 KB apart (an immediate offset of the store).
@@ -285,18 +287,22 @@ __device__ __forceinline__ int kfrag_index(int ns, int c, int k, int d) {
     return ((((k >> 3) * ns + d) * 64 + ((k & 3) << 4) + c) << 1) + ((k >> 2) & 1);
 }
 
+// pairs [begin, end) of worker `w` out of `total` pairs, for workers of the given weights (cumulative weight before w,
+// own weight, weight sum): proportional shares, every pair exactly once
+__device__ __forceinline__ void kstar_pair_range(int total, int before, int weight, int wsum, int& begin, int& end) {
+    begin = total * before / wsum;
+    end = total * (before + weight) / wsum;
+}
+
 typedef __attribute__((address_space(3))) double lds_f64;
 
 template <int NS, int D>
-__device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int nworkers,
-                                               int worker) {
+__device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int q_begin, int q_end) {
     const int lane = (int)threadIdx.x & 63;
     const int c = lane & 15;
     double z[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) z[j] = lds.zs[c * D + j];
-    const int kstep = 4 * nworkers;
-    const int k0 = 4 * worker + (lane >> 4);
     // loop invariants the compiler would otherwise re-materialise from SGPRs on every trip (VOP3 takes one SGPR)
     double log_os[NS];
 #pragma unroll
@@ -310,17 +316,21 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
     for (int j = 0; j < D; ++j) znan = znan || (z[j] != z[j]);
     const lds_f64* etab = (const lds_f64*)lds.etab + (znan ? kExpTab : 0);
 
-    // M = 1 or 2 training points of this thread at once: M NS independent exp chains in flight
-    auto eval = [&](auto mtag, const lds_f64* x0, const lds_f64* x1, lds_f64* f0, lds_f64* f1) {
-        constexpr int M = decltype(mtag)::value;
-        double arg[M * NS], val[M * NS];
+    // 32-bit LDS pointers, advanced by a constant per trip and hidden from the optimiser, which would otherwise turn
+    // them back into base + offset and spend an add per access
+    const int k0 = 8 * q_begin + (lane >> 4);
+    const lds_f64* x = (const lds_f64*)lds.xs + k0 * D;
+    lds_f64* f = (lds_f64*)lds.kfrag + kfrag_index(NS, c, k0, 0);
+    for (int q = q_begin; q < q_end; ++q) {
+        asm volatile("" : "+v"(x), "+v"(f));
+        // the two rows of this thread at once: 2 NS independent exp chains in flight
+        double arg[2 * NS], val[2 * NS];
 #pragma unroll
-        for (int h = 0; h < M; ++h) {
-            const lds_f64* xr = h ? x1 : x0;
+        for (int h = 0; h < 2; ++h) {
             double sq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const double df = z[j] - xr[j];
+                const double df = z[j] - x[h * 4 * D + j];
                 sq[j] = df * df;
             }
 #pragma unroll
@@ -331,37 +341,15 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
                 arg[h * NS + d] = a;
             }
         }
-        exp_tab_f64_n<M * NS>(arg, val, etab);
+        exp_tab_f64_n<2 * NS>(arg, val, etab);
 #pragma unroll
-        for (int h = 0; h < M; ++h) {
-            lds_f64* f = h ? f1 : f0;
-#pragma unroll
-            for (int d = 0; d < NS; ++d) f[d * 128] = val[h * NS + d];
+        for (int d = 0; d < NS; ++d) {
+            f[d * 128] = val[d];           // slot 0: row 8 q + kk
+            f[d * 128 + 1] = val[NS + d];  // slot 1: row 8 q + kk + 4
         }
-    };
-
-    // 32-bit LDS pointers, advanced by a constant per trip and hidden from the optimiser, which would otherwise turn
-    // them back into base + offset and spend an add per access
-    const lds_f64* x0 = (const lds_f64*)lds.xs + k0 * D;
-    const lds_f64* x1 = x0 + kstep * D;
-    lds_f64* f0 = (lds_f64*)lds.kfrag + kfrag_index(NS, c, k0, 0);
-    lds_f64* f1 = (lds_f64*)lds.kfrag + kfrag_index(NS, c, k0 + kstep, 0);
-    const int xadv = 2 * kstep * D, fadv = kstep * NS * 32;
-    // trips in which every thread has two points below n_pad: no conditions at all
-    const int nfull = gc.n_pad / (2 * kstep);
-    for (int trip = 0; trip < nfull; ++trip) {
-        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(f0), "+v"(f1));
-        eval(std::integral_constant<int, 2>{}, x0, x1, f0, f1);
-        x0 += xadv;
-        x1 += xadv;
-        f0 += fadv;
-        f1 += fadv;
+        x += 8 * D;
+        f += NS * 128;
     }
-    const int k = nfull * 2 * kstep + k0;
-    if (k + kstep < gc.n_pad)
-        eval(std::integral_constant<int, 2>{}, x0, x1, f0, f1);
-    else if (k < gc.n_pad)
-        eval(std::integral_constant<int, 1>{}, x0, x0, f0, f0);
 }
 
 // Phase 2: the triangular products on the matrix cores.

@@ -45,7 +45,9 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
             lds.zs[tid] = (g0 + c < P) ? z[(int64_t)(g0 + c) * D + j] : 0.0;
         }
         __syncthreads();
-        gp_kstar_phase(gc, lds, nw, wave);
+        int qb, qe;
+        kstar_pair_range(gc.n_pad >> 3, wave, 1, nw, qb, qe);
+        gp_kstar_phase(gc, lds, qb, qe);
         __syncthreads();
         gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head);
         __syncthreads();

@@ -180,16 +180,26 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0, c_e = 0, c_eb = 0;
 #endif
     const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane);
+    // Kstar shares (pairs of fragments).  Step 0: all waves alike.  From step 1 on wave 0 runs finish(); waves w and w + 4
+    // share a SIMD, so wave 4 competes with finish() for its pipe and gets half a share (weight 1 against 2).
+    int q0_begin, q0_end, q_begin = 0, q_end = 0;
+    kstar_pair_range(gc.n_pad >> 3, wave, 1, nw, q0_begin, q0_end);
+    if (wave > 0) {
+        const bool shares = nw > 4;
+        const int before = 2 * (wave - 1) - ((shares && wave > 4) ? 1 : 0);
+        const int weight = (shares && wave == 4) ? 1 : 2;
+        kstar_pair_range(gc.n_pad >> 3, before, weight, 2 * (nw - 1) - (shares ? 1 : 0), q_begin, q_end);
+    }
     for (int t = 0; t < H; ++t) {
 #ifdef SX_STAMPS
         const unsigned long long t0 = stamp();
 #endif
         if (t == 0) {
-            gp_kstar_phase(gc, lds, nw, wave);
+            gp_kstar_phase(gc, lds, q0_begin, q0_end);
         } else if (wave == 0) {
             if (owner) finish(t - 1);
         } else {
-            gp_kstar_phase(gc, lds, nw - 1, wave - 1);
+            gp_kstar_phase(gc, lds, q_begin, q_end);
         }
 #ifdef SX_STAMPS
         const unsigned long long t1 = stamp();

@@ -203,7 +203,7 @@ struct GpTileLds {
     double* kfrag;  // [NS][n_pad x 16]   Kstar in fragment order
     double* mj;     // [NS][16 rows][16]  mean / Jacobian rows
     double* part;   // [NW][NS][16]       per-wave partial sums of squares
-    double* zs;     // [16][D]            query points
+    double* zs;     // [2][16][D]         query points (the rollout alternates between the halves; predict uses the first)
     double* etab;   // [512]              2^(j/256) for exp_tab_f64_n, then 256 NaNs (the table of a NaN query point)
     __device__ double* carve(double* base, int n_train, int n_pad, int nw) {
         xs = base;
@@ -211,7 +211,7 @@ struct GpTileLds {
         mj = kfrag + (size_t)NS * n_pad * 16;
         part = mj + NS * 256;
         zs = part + (size_t)nw * NS * 16;
-        etab = zs + 16 * D;
+        etab = zs + 32 * D;
         return etab + 2 * kExpTab;
     }
 };
@@ -256,7 +256,7 @@ inline int gp_stage_cap(int ns, int n_pad, int nw) {
 inline int64_t gp_stage_tab_ints(int ns, int n_pad, int nw) { return 4 * (int64_t)nw * (1 + gp_stage_cap(ns, n_pad, nw)); }
 
 inline size_t gp_tile_lds_doubles(int ns, int d, int n_train, int n_pad, int nw) {
-    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 16 * d + 2 * kExpTab;
+    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 32 * d + 2 * kExpTab;
 }
 
 template <int NS, int D>
@@ -297,12 +297,11 @@ __device__ __forceinline__ void kstar_pair_range(int total, int before, int weig
 typedef __attribute__((address_space(3))) double lds_f64;
 
 template <int NS, int D>
-__device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int q_begin, int q_end) {
+__device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int q_begin, int q_end,
+                                               const double (&z)[D]) {
+    // z: the query point of this thread's c = lane & 15 (the caller loads or derives it)
     const int lane = (int)threadIdx.x & 63;
     const int c = lane & 15;
-    double z[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) z[j] = lds.zs[c * D + j];
     // loop invariants the compiler would otherwise re-materialise from SGPRs on every trip (VOP3 takes one SGPR)
     double log_os[NS];
 #pragma unroll

@@ -47,7 +47,10 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
         __syncthreads();
         int qb, qe;
         kstar_pair_range(gc.n_pad >> 3, wave, 1, nw, qb, qe);
-        gp_kstar_phase(gc, lds, qb, qe);
+        double zq[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) zq[j] = lds.zs[(lane & 15) * D + j];
+        gp_kstar_phase(gc, lds, qb, qe, zq);
         __syncthreads();
         gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head);
         __syncthreads();

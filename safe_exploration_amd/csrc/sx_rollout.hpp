@@ -102,25 +102,25 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     }
     __syncthreads();
 
-    // Step t:   Kstar(t)  |sync|  MFMA(t)  |sync|  quick(t): p_{t+1} = mean + a p + b u  ->  zs  |sync|
-    // The rest of step t (variance, Jacobian, ellipsoid algebra, costs: ~4.5k cycles on 16 lanes) does not feed
+    // Step t:   Kstar(t)  |sync|  MFMA(t)  |sync|
+    // The next centre p_{t+1} = mean + a p + b u is not a phase of its own: every Kstar thread derives the centre of
+    // ITS query point at the start of Kstar(t+1) from z_t (LDS) and the posterior mean MFMA(t) left in LDS -- a dozen
+    // FMAs, redundantly, in the slack the Kstar waves have against finish().  z lives in two LDS buffers: buffer t & 1
+    // holds z_t = (p_t, u_t); finish(t-1), which derives the same p_t (same fma chain, bit-identical) during
+    // Kstar(t), writes z_t into it for the threads of step t + 1.
+    // The rest of step t (variance, Jacobian, ellipsoid algebra, costs: ~4.2k cycles on 16 lanes) does not feed
     // Kstar(t+1), so wave 0 runs it DURING Kstar(t+1) while waves 1..7 compute the kernel rows.
-    double pn[NS];  // p_{t+1} from quick(t), kept for finish(t)
-    auto quick = [&](int t) {
+    double* const zs_base = lds.zs;
+    // centre of particle c at step t >= 1 from z_{t-1} and the means of step t - 1
+    auto next_centre = [&](int c, const double* z_prev, double (&out)[NS]) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            double s = lds.mj[i * 256 + tid];  // posterior mean of output i
+            double s = lds.mj[i * 256 + c];  // posterior mean of output i
 #pragma unroll
-            for (int j = 0; j < NS; ++j) s += rc.a[i * NS + j] * p[j];
+            for (int j = 0; j < NS; ++j) s = fma(rc.a[i * NS + j], z_prev[j], s);
 #pragma unroll
-            for (int cidx = 0; cidx < NU; ++cidx) s += rc.b[i * NU + cidx] * acts[(tid * H + t) * NU + cidx];
-            pn[i] = s;
-        }
-        if (t + 1 < H) {
-#pragma unroll
-            for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = pn[i];
-#pragma unroll
-            for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
+            for (int cidx = 0; cidx < NU; ++cidx) s = fma(rc.b[i * NU + cidx], z_prev[NS + cidx], s);
+            out[i] = s;
         }
     };
     auto finish = [&](int t) {
@@ -141,8 +141,22 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
             reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st_step);
         }
         have_q = true;
+        {
+            // exactly the centre the next GP query uses (same chain as next_centre), published for the step after it
+            double zt[D];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) p1[i] = pn[i];  // exactly the centre the next GP query used
+            for (int j = 0; j < NS; ++j) zt[j] = p[j];
+#pragma unroll
+            for (int cidx = 0; cidx < NU; ++cidx) zt[NS + cidx] = u[cidx];
+            next_centre(tid, zt, p1);
+            if (t + 1 < H) {
+                double* zn = zs_base + ((t + 1) & 1) * 16 * D + tid * D;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) zn[i] = p1[i];
+#pragma unroll
+                for (int cidx = 0; cidx < NU; ++cidx) zn[NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
+            }
+        }
         if (valid) st |= st_step;
         // costs (safempc_cem.py:102-132,304-312; action constraint: test_safempc_cem.py:59-71)
         obj += objective_cost<SX_MAX_M, NS, NU>(cc, p1, var);
@@ -178,6 +192,10 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 
 #ifdef SX_STAMPS
     unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0, c_e = 0, c_eb = 0;
+    // shader clock against the constant 100 MHz reference: is the chip holding its clock under this kernel?
+    unsigned long long rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+    const unsigned long long ct0 = stamp();
 #endif
     const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane);
     // Kstar shares (pairs of fragments).  Step 0: all waves alike.  From step 1 on wave 0 runs finish(); waves w and w + 4
@@ -194,12 +212,24 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 #ifdef SX_STAMPS
         const unsigned long long t0 = stamp();
 #endif
-        if (t == 0) {
-            gp_kstar_phase(gc, lds, q0_begin, q0_end);
-        } else if (wave == 0) {
+        if (t > 0 && wave == 0) {
             if (owner) finish(t - 1);
         } else {
-            gp_kstar_phase(gc, lds, q_begin, q_end);
+            const int c = lane & 15;
+            double zq[D];
+            if (t == 0) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) zq[j] = zs_base[c * D + j];
+                gp_kstar_phase(gc, lds, q0_begin, q0_end, zq);
+            } else {
+                double pc[NS];
+                next_centre(c, zs_base + ((t - 1) & 1) * 16 * D + c * D, pc);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) zq[i] = pc[i];
+#pragma unroll
+                for (int cidx = 0; cidx < NU; ++cidx) zq[NS + cidx] = acts[(c * H + t) * NU + cidx];
+                gp_kstar_phase(gc, lds, q_begin, q_end, zq);
+            }
         }
 #ifdef SX_STAMPS
         const unsigned long long t1 = stamp();
@@ -215,15 +245,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
         __syncthreads();
 #ifdef SX_STAMPS
         const unsigned long long t4 = stamp();
-#endif
-        if (owner) quick(t);
-#ifdef SX_STAMPS
-        const unsigned long long t5 = stamp();
-#endif
-        __syncthreads();
-#ifdef SX_STAMPS
-        const unsigned long long t6 = stamp();
-        c_k += t1 - t0; c_kb += t2 - t1; c_m += t3 - t2; c_mb += t4 - t3; c_e += t5 - t4; c_eb += t6 - t5;
+        c_k += t1 - t0; c_kb += t2 - t1; c_m += t3 - t2; c_mb += t4 - t3;
 #endif
     }
     if (owner) finish(H - 1);
@@ -231,6 +253,10 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     if (g_stamp_buf && lane == 0) {
         unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * nw + wave) * 8;
         o[0] = c_k; o[1] = c_kb; o[2] = c_m; o[3] = c_mb; o[4] = c_e; o[5] = c_eb;
+        unsigned long long rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+        o[6] = stamp() - ct0;   // shader cycles of the step loop
+        o[7] = rt1 - rt0;       // the same span in 10 ns ticks
     }
 #endif
     if (valid) {

@@ -32,7 +32,10 @@ noise = torch.randn((1, P, H, 1), dtype=torch.float64, device=dev)
 for _ in range(3):
     cem_rollout(ssm, env, x0, H, mean=mean, std=std, noise=noise)
 torch.cuda.synchronize()
-s = buf.cpu().numpy().reshape(nwg, nw, 8)[:, :, :6].astype(np.float64) / H
+raw = buf.cpu().numpy().reshape(nwg, nw, 8).astype(np.float64)
+s = raw[:, :, :6] / H
+clk = np.median(raw[:, 0, 6] / (raw[:, 0, 7] * 10.0))
+print(f'shader clock while the kernel runs: {clk:.2f} GHz (s_memtime cycles per s_memrealtime tick; all {nwg} workgroups resident)')
 names = ['kstar', 'kstar->barrier', 'mfma', 'mfma->barrier', 'epilogue', 'epilogue->barrier']
 print(f'cycles per step (median over {nwg} workgroups), per wave:')
 for w in range(nw):

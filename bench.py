@@ -28,6 +28,19 @@ def algorithmic_flops_per_particle_step(n_s, n_train, d_in):
 F64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; DESIGN.md "Roofline"
 
 
+def pmc_mfma_instructions(workload_key):
+    """v_mfma_f64_16x16x4 instructions per launch of the dominant kernel (SQ_INSTS_MFMA, same committed PMC passes), or
+    None: 2048 flop each -- what the kernel EXECUTES, as opposed to the algorithmic count the roofline contract uses."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
+            d = json.load(f)
+        if d.get('workload') == workload_key:
+            return d['per_launch_averages']['cem_rollout_kernel<2,1>']['SQ_INSTS_MFMA']
+    except Exception:
+        pass
+    return None
+
+
 def pmc_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), or None.
     bench.py cannot collect PMC counters itself; the number is only reported for the workload it was collected on."""
@@ -142,6 +155,8 @@ def main():
         flops_unit = algorithmic_flops_per_particle_step(spec.n_s, args.n_train, spec.n_s + spec.n_u)
         achieved = flops_unit * P * H / avg_rollout_s / 1e12
         traffic = pmc_traffic(f'cfg2 pendulum N_train={args.n_train} H={H} P={P}')
+        n_mfma = pmc_mfma_instructions(f'cfg2 pendulum N_train={args.n_train} H={H} P={P}')
+        executed = (n_mfma * 2048 / avg_rollout_s / 1e12) if n_mfma else None
         out = {
             'metric': 'cem_particle_step_evals_per_s', 'value': particle_steps / elapsed, 'unit': 'particle-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -161,7 +176,10 @@ def main():
                          'avg_launch_us': avg_rollout_s * 1e6, 'launches_timed': len(rollout_ms),
                          'hbm_gb_per_s': (traffic / avg_rollout_s / 1e9) if traffic else None,
                          'hbm_frac_of_8TBps': (traffic / avg_rollout_s / 8e12) if traffic else None,
-                         'algorithmic_flops_per_launch': flops_unit * P * H},
+                         'algorithmic_flops_per_launch': flops_unit * P * H,
+                         # the triangular form executes about half the algorithmic flops: the matrix pipe's real load
+                         'executed_tflops': executed,
+                         'executed_frac': (executed / F64_MATRIX_PEAK_TFLOPS) if executed else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(spec, H, P, max(1, P // 10))

@@ -86,8 +86,8 @@ def cpu_baseline(spec, horizon, particles, elites, budget_s=12.0, max_iters=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--particles', type=int, default=4096, help='per GPU')
     ap.add_argument('--horizon', type=int, default=15)
     ap.add_argument('--n-train', type=int, default=200)

@@ -193,12 +193,16 @@ __global__ __launch_bounds__(kBigThreads) void trmm_reduce_kernel(GpConst<NS, D>
 #pragma unroll
             for (int n = 0; n < 4; ++n) b[n] = sB[4 * wc + n][pr][lane];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) {
+                // beyond the diagonal of row-block rb0 + 4 wr + m its W fragments are zero padding: nothing to add
+                // (wave-uniform; only the last chunks of a tile's K extent are affected)
+                if (q0 + pr >= 2 * (rb0 + 4 * wr + m + 1)) continue;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
                 }
+            }
         }
         __syncthreads();
     }

@@ -94,9 +94,20 @@ __global__ void init_big_kernel(BigInit bi, BigWs ws, int64_t total, int64_t p12
 template <int NS, int D>
 __global__ __launch_bounds__(256) void kstar_big_kernel(GpConst<NS, D> gc, BigWs ws) {
     const int tile = blockIdx.x, c = threadIdx.x & 15;
+    // the table-driven exp of the fused path (sx_gp.hpp): 2^(j/256) in LDS, behind it the NaN table of a NaN query
+    __shared__ double etab_s[2 * kExpTab];
+    etab_s[threadIdx.x] = kExp2Tab[threadIdx.x];
+    etab_s[kExpTab + threadIdx.x] = __builtin_nan("");
+    static_assert(kExpTab == 256, "one table entry per thread of this kernel");
     double z[D];
+    bool znan = false;
 #pragma unroll
-    for (int j = 0; j < D; ++j) z[j] = ws.zs[((int64_t)tile * 16 + c) * D + j];
+    for (int j = 0; j < D; ++j) {
+        z[j] = ws.zs[((int64_t)tile * 16 + c) * D + j];
+        znan = znan || (z[j] != z[j]);
+    }
+    __syncthreads();
+    const lds_f64* etab = (const lds_f64*)etab_s + (znan ? kExpTab : 0);
     const int64_t tstride = (int64_t)(gc.n_pad >> 3) * 128;
     const int64_t dstride = (int64_t)gridDim.x * tstride;
     const int kbase = blockIdx.y * 256;
@@ -116,13 +127,13 @@ __global__ __launch_bounds__(256) void kstar_big_kernel(GpConst<NS, D> gc, BigWs
             }
 #pragma unroll
             for (int d = 0; d < NS; ++d) {
-                double a = gc.log_os[d];
+                double a = gc.k_log_os[d];   // exponent in units of ln 2 / 256
 #pragma unroll
-                for (int j = 0; j < D; ++j) a = fma(sq[j], gc.nh_ils2[d * D + j], a);
+                for (int j = 0; j < D; ++j) a = fma(sq[j], gc.k_nh_ils2[d * D + j], a);
                 arg[h * NS + d] = a;
             }
         }
-        exp_f64_n<2 * NS>(arg, val);
+        exp_tab_f64_n<2 * NS>(arg, val, etab);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (ks[h] < gc.n_pad) {

@@ -115,11 +115,12 @@ constexpr double kExpUnit = 0.693147180559945309417232 / 256.0;    // ln 2 / 256
 // e^x for M arguments at once, table-driven; the caller passes y = x * 256 / ln 2 (it folds the factor into the
 // constants that produce x).  y = 256 n + j + f, |f| <= 1/2, so e^x = 2^n T[j] e^r with r = f ln2/256, |r| <= ln2/512:
 // T from LDS (`tab`, 256 doubles), e^r - 1 by a degree-4 polynomial (truncation 4e-17).  14 VALU instructions and one
-// LDS read per value against 19 for the polynomial-only form below; error <= ~1 ulp on top of the rounding of y itself
+// LDS read per value (a polynomial-only exp with the same accuracy needs 19); error <= ~1 ulp on top of the rounding of y itself
 // (|x| 2e-16, the same as rounding x would cost).  Below e^-800 the result is 0 whatever the argument (also -inf, also
 // 1e300 lengthscales away): the clamp keeps the reduction exact for every input.  A NaN argument does NOT give NaN
 // (max drops it): callers that must propagate NaN pass a table of NaNs (gp_kstar_phase does).  The M chains advance
-// in lock-step for the reason given below.
+// in lock-step: a dependent f64 op issues every ~9 cycles, an independent one every ~4 (tools/valu_probe.hip), and the
+// f64 VALU is the unit this kernel's MFMAs compete with.
 template <int M>
 __device__ __forceinline__ void exp_tab_f64_n(const double (&y)[M], double (&out)[M],
                                               const __attribute__((address_space(3))) double* tab) {
@@ -145,38 +146,6 @@ __device__ __forceinline__ void exp_tab_f64_n(const double (&y)[M], double (&out
     for (int i = 0; i < M; ++i) p[i] = p[i] * r[i];
 #pragma unroll
     for (int i = 0; i < M; ++i) out[i] = ldexp(fma(t[i], p[i], t[i]), mi[i] >> 8);
-}
-
-// e^x for M finite arguments at once (here x <= ln(outputscale)): round-to-nearest range reduction x = n ln2 + r,
-// |r| <= ln2 / 2, degree-13 Taylor polynomial (truncation 4e-18), ldexp: 19 VALU instructions per value, error <= ~2 ulp
-// (-inf / NaN give NaN).  The M Horner chains advance in lock-step: a dependent f64 op issues every ~9 cycles, an
-// independent one every ~4 (tools/valu_probe.hip), and the f64 VALU is the unit this kernel's MFMAs compete with.
-template <int M>
-__device__ __forceinline__ void exp_f64_n(const double (&x)[M], double (&out)[M]) {
-    constexpr double c[12] = {1.6059043836821613e-10,  2.08767569878680989792e-09, 2.50521083854417187751e-08,
-                              2.75573192239858906526e-07, 2.75573192239858906526e-06, 2.48015873015873015873e-05,
-                              1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03,
-                              4.16666666666666666667e-02, 1.66666666666666666667e-01, 0.5};  // 1/13! .. 1/2!
-    double n[M], r[M], p[M];
-#pragma unroll
-    for (int i = 0; i < M; ++i) n[i] = __builtin_rint(x[i] * 1.44269504088896338700e+00);
-#pragma unroll
-    for (int i = 0; i < M; ++i) r[i] = fma(n[i], -6.93147180369123816490e-01, x[i]);
-#pragma unroll
-    for (int i = 0; i < M; ++i) r[i] = fma(n[i], -1.90821492927058770002e-10, r[i]);
-#pragma unroll
-    for (int i = 0; i < M; ++i) p[i] = c[0];
-#pragma unroll
-    for (int t = 1; t < 12; ++t) {
-#pragma unroll
-        for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], c[t]);
-    }
-#pragma unroll
-    for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 1.0);
-#pragma unroll
-    for (int i = 0; i < M; ++i) p[i] = fma(p[i], r[i], 1.0);
-#pragma unroll
-    for (int i = 0; i < M; ++i) out[i] = ldexp(p[i], (int)n[i]);
 }
 
 template <int NS, int D>

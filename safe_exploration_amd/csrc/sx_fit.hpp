@@ -268,8 +268,13 @@ __global__ __launch_bounds__(kFitThreads) void gp_mll_grad_kernel(MllArgs ma) {
     }
 }
 
-__global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap) {
-    if ((int)threadIdx.x < nw) gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x);
+// the combined table (all outputs), then one table per output (sx_rollout.hpp, output-by-output mode)
+__global__ void build_stage_tab_kernel(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap, int stage_cap_one) {
+    if ((int)threadIdx.x >= nw) return;
+    gp_build_stage_tab(tab, ns, n_train, n_pad, nw, stage_cap, threadIdx.x);
+    int4* one = tab + (size_t)nw * (1 + stage_cap);
+    for (int d = 0; d < ns; ++d)
+        gp_build_stage_tab(one + (size_t)d * nw * (1 + stage_cap_one), 1, n_train, n_pad, nw, stage_cap_one, threadIdx.x, d);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -162,7 +162,9 @@ struct GpConst {
     const int4* stage_tab;   // [nw] headers {stage count}, then [nw][stage_cap] stage descriptors
     int n_train;
     int n_pad;
-    int stage_cap;  // gp_stage_cap(NS, n_pad, waves per workgroup)
+    int stage_cap;      // gp_stage_cap(NS, n_pad, waves per workgroup)
+    int stage_cap_one;  // gp_stage_cap(1, ...): the per-output streams of the output-by-output rollout, which follow the
+                        // combined table in the same buffer: table d at stage_tab + nw (1 + stage_cap) + d nw (1 + stage_cap_one)
 };
 
 // LDS carve-up of one GP tile (all in doubles, 16-byte aligned pieces)
@@ -174,10 +176,11 @@ struct GpTileLds {
     double* part;   // [NW][NS][16]       per-wave partial sums of squares
     double* zs;     // [2][16][D]         query points (the rollout alternates between the halves; predict uses the first)
     double* etab;   // [512]              2^(j/256) for exp_tab_f64_n, then 256 NaNs (the table of a NaN query point)
-    __device__ double* carve(double* base, int n_train, int n_pad, int nw) {
+    // ns_lds: outputs whose Kstar is in LDS at the same time (NS, or 1 in the output-by-output rollout)
+    __device__ double* carve(double* base, int n_train, int n_pad, int nw, int ns_lds = NS) {
         xs = base;
         kfrag = xs + ((n_pad * D + 1) & ~1);
-        mj = kfrag + (size_t)NS * n_pad * 16;
+        mj = kfrag + (size_t)ns_lds * n_pad * 16;
         part = mj + NS * 256;
         zs = part + (size_t)nw * NS * 16;
         etab = zs + 32 * D;
@@ -222,10 +225,14 @@ inline int gp_stage_cap(int ns, int n_pad, int nw) {
     return cap + kStagePad;
 }
 
-inline int64_t gp_stage_tab_ints(int ns, int n_pad, int nw) { return 4 * (int64_t)nw * (1 + gp_stage_cap(ns, n_pad, nw)); }
+// the combined table, then one table per output
+inline int64_t gp_stage_tab_ints(int ns, int n_pad, int nw) {
+    return 4 * (int64_t)nw * ((1 + gp_stage_cap(ns, n_pad, nw)) + (int64_t)ns * (1 + gp_stage_cap(1, n_pad, nw)));
+}
 
-inline size_t gp_tile_lds_doubles(int ns, int d, int n_train, int n_pad, int nw) {
-    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 32 * d + 2 * kExpTab;
+inline size_t gp_tile_lds_doubles(int ns, int d, int n_train, int n_pad, int nw, int ns_lds = -1) {
+    if (ns_lds < 0) ns_lds = ns;
+    return (size_t)((n_pad * d + 1) & ~1) + (size_t)ns_lds * n_pad * 16 + ns * 256 + (size_t)nw * ns * 16 + 32 * d + 2 * kExpTab;
 }
 
 template <int NS, int D>
@@ -320,6 +327,43 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
     }
 }
 
+// The same for ONE output DD, into a Kstar buffer that holds a single output ([pair][lane][slot]): the
+// output-by-output rollout for training sets whose n_s Kstar buffers do not fit in LDS together.
+template <int NS, int D, int DD>
+__device__ __forceinline__ void gp_kstar_phase_one(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int q_begin, int q_end,
+                                                   const double (&z)[D]) {
+    const int lane = (int)threadIdx.x & 63;
+    const int c = lane & 15;
+    double log_os = gc.k_log_os[DD];
+    asm volatile("" : "+v"(log_os));
+    bool znan = false;
+#pragma unroll
+    for (int j = 0; j < D; ++j) znan = znan || (z[j] != z[j]);
+    const lds_f64* etab = (const lds_f64*)lds.etab + (znan ? kExpTab : 0);
+    const int k0 = 8 * q_begin + (lane >> 4);
+    const lds_f64* x = (const lds_f64*)lds.xs + k0 * D;
+    lds_f64* f = (lds_f64*)lds.kfrag + kfrag_index(1, c, k0, 0);
+    for (int q = q_begin; q < q_end; ++q) {
+        asm volatile("" : "+v"(x), "+v"(f));
+        double arg[2], val[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double a = log_os;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double df = z[j] - x[h * 4 * D + j];
+                a = fma(df * df, gc.k_nh_ils2[DD * D + j], a);
+            }
+            arg[h] = a;
+        }
+        exp_tab_f64_n<2>(arg, val, etab);
+        f[0] = val[0];
+        f[1] = val[1];
+        x += 8 * D;
+        f += 128;
+    }
+}
+
 // Phase 2: the triangular products on the matrix cores.
 //
 // A wave's share of the work is static, so sx_gp_pack writes it once (build_stage_tab_kernel) to global memory as a
@@ -338,8 +382,11 @@ constexpr int kStageLast = 2, kStageExtra = 4;
 
 // one thread per wave (warm path): replay the assignment and write that wave's stream.
 // tab = [nw] headers {stage count}, then [nw][stage_cap] descriptors
+// The stream covers the outputs d_first .. d_first + ns - 1, whose Kstar sits in LDS side by side ([pair][ns][lane]):
+// all of them in the fused kernel (d_first = 0), one at a time in the output-by-output kernel (ns = 1).  `ns_total`
+// is the model's output count (it sets where an output's W fragments start).
 __device__ __forceinline__ void gp_build_stage_tab(int4* tab, int ns, int n_train, int n_pad, int nw, int stage_cap,
-                                                   int wave) {
+                                                   int wave, int d_first = 0) {
     const int nrb = n_pad >> 4;
     const int ntask = ns * nrb;
     const int wpo = (int)w_pairs_per_output(nrb);
@@ -362,11 +409,12 @@ __device__ __forceinline__ void gp_build_stage_tab(int4* tab, int ns, int n_trai
         load[target] += cost;
         if (target != wave) continue;
         const int rb = nrb - 1 - j / ns;
-        const int d = j % ns;
+        const int dl = j % ns;          // position of the output's Kstar in LDS
+        const int d = d_first + dl;     // the output itself
         const int a0 = d * wpo + rb * (rb + 1);
         const int extra = (16 * rb + 15 >= n_train) ? kStageExtra : 0;  // block holds mean/Jacobian (or padding) rows
         for (int q = 0; q < npairs; q += 2, ++pos)
-            out[pos] = int4{a0 + q, (q * ns + d) * 64, d | (rb << 8), extra | ((q + 2 >= npairs) ? kStageLast : 0)};
+            out[pos] = int4{a0 + q, (q * ns + dl) * 64, d | (rb << 8), extra | ((q + 2 >= npairs) ? kStageLast : 0)};
     }
     // dummy descriptors (valid addresses, never computed on) behind the stream
     for (int i = 0; i < kStagePad; ++i) out[pos + i] = int4{0, 0, 0, 0};
@@ -392,10 +440,10 @@ struct MfmaHead {
 
 template <int NS, int D>
 __device__ __forceinline__ MfmaHead gp_mfma_head(const GpConst<NS, D>& gc, const int4* __restrict__ stage_tab, int wave,
-                                                 int nw, int lane) {
+                                                 int nw, int lane, int stage_cap) {
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     // (a stream is followed by kStagePad valid dummy descriptors, so four stages can always be requested)
-    const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * gc.stage_cap;
+    const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * stage_cap;
     const __amdgpu_buffer_rsrc_t arsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gc.a_pack), 0, (int)0xffffffffu, 0x00020000);
     MfmaHead h;
@@ -416,10 +464,12 @@ __device__ __forceinline__ MfmaHead gp_mfma_head(const GpConst<NS, D>& gc, const
     return h;
 }
 
-template <int NS, int D>
+// NSL: outputs side by side in the LDS Kstar (NS, or 1); only_d >= 0: the stream holds that output alone, and only its
+// partial sum is written.
+template <int NS, int D, int NSL = NS>
 __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const int4* __restrict__ stage_tab,
                                               GpTileLds<NS, D>& lds, int wave, int nw, int lane,
-                                              const MfmaHead& head) {
+                                              const MfmaHead& head, int stage_cap, int only_d = -1) {
     double ssq[NS];
 #pragma unroll
     for (int d = 0; d < NS; ++d) ssq[d] = 0.0;
@@ -427,7 +477,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     // stage_tab is a __restrict__ kernel argument of its own: the loads below are provably unclobbered and uniform,
     // which is what lets the compiler issue them as s_load
-    const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * gc.stage_cap;
+    const int4* __restrict__ stages = stage_tab + nw + (size_t)swave * stage_cap;
     const int nst = head.nst;
     // A fragments through a buffer descriptor: address = SGPR base + SGPR stage offset + constant per-lane offset,
     // so a load needs no vector arithmetic at all
@@ -463,7 +513,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         st.a1 = head.a[i][1];
         const v2d* b = kbase + head.y[i];
         st.b0 = b[0];
-        st.b1 = b[64 * NS];
+        st.b1 = b[64 * NSL];
     };
 
     // one accumulator: a dependent chain of this MFMA issues at the full rate (tools/mfma_probe.hip)
@@ -483,7 +533,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.x, cur.b1.x, acc, 0, 0, 0);
         SX_PIN();
         nx.b0 = bp[0];
-        nx.b1 = bp[64 * NS];
+        nx.b1 = bp[64 * NSL];
         SX_PIN();
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a1.y, cur.b1.y, acc, 0, 0, 0);
         SX_PIN();
@@ -539,6 +589,7 @@ __device__ __forceinline__ void gp_mfma_phase(const GpConst<NS, D>& gc, const in
     // more MFMA per output instead of two dependent cross-lane shuffles through LDS.
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
+        if (only_d >= 0 && only_d != d) continue;   // (uniform)
         const v4d tot = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, ssq[d], v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
         if (lane < 16) lds.part[(wave * NS + d) * 16 + lane] = tot[0];
     }

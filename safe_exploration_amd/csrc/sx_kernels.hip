@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     gp_load_xs(gc, lds);
-    const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane);
+    const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane, gc.stage_cap);
     for (int tile = blockIdx.x; tile * SX_TILE < P; tile += gridDim.x) {
         const int g0 = tile * SX_TILE;
         if (tid < SX_TILE * D) {
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
         for (int j = 0; j < D; ++j) zq[j] = lds.zs[(lane & 15) * D + j];
         gp_kstar_phase(gc, lds, qb, qe, zq);
         __syncthreads();
-        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head);
+        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head, gc.stage_cap);
         __syncthreads();
         if (tid < SX_TILE && g0 + tid < P) {
             double zz[D], m[NS], v[NS], jc[NS][D];
@@ -173,6 +173,7 @@ static GpConst<NS, NS + NU> make_gp_const(const sx_gp_model* m, int nw) {
     gc.n_train = m->n_train;
     gc.n_pad = m->n_pad;
     gc.stage_cap = gp_stage_cap(NS, m->n_pad, nw);
+    gc.stage_cap_one = gp_stage_cap(1, m->n_pad, nw);
     return gc;
 }
 
@@ -356,10 +357,12 @@ static int launch_predict_big(const sx_gp_model* m, const double* z, int P, doub
     return check_launch();
 }
 
-// does the fused kernel's LDS budget hold Kstar for this model?
-static bool fused_fits(int ns, int nu, int n_train, int n_pad, int H) {
+// does the single-launch kernel's LDS budget hold Kstar for this model -- of all outputs at once (ns_lds = ns), or of one
+// output at a time (ns_lds = 1)?
+static bool fused_fits(int ns, int nu, int n_train, int n_pad, int H, int ns_lds = -1) {
     const int nw = kRolloutThreads / 64;
-    const size_t lds = (gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw) + (size_t)SX_TILE * H * nu) * sizeof(double);
+    const size_t lds =
+        (gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw, ns_lds) + (size_t)SX_TILE * H * nu) * sizeof(double);
     return lds <= kMaxLdsBytes && n_pad <= 1024;
 }
 
@@ -396,7 +399,8 @@ static int launch_rollout_big(const sx_gp_model* m, const sx_env* env, const Rol
 template <int NS, int NU>
 static int launch_rollout(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, double* workspace,
                           int64_t workspace_bytes, hipStream_t stream) {
-    if (!fused_fits(NS, NU, m->n_train, m->n_pad, rp.H))
+    const bool all_at_once = fused_fits(NS, NU, m->n_train, m->n_pad, rp.H);
+    if (!all_at_once && !(NS > 1 && fused_fits(NS, NU, m->n_train, m->n_pad, rp.H, 1)))
         return launch_rollout_big<NS, NU>(m, env, rp, workspace, workspace_bytes, stream);
     const int nw = kRolloutThreads / 64;
     auto gc = make_gp_const<NS, NU>(m, nw);
@@ -404,12 +408,18 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
     if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
     CostConst<SX_MAX_M, NS, NU> cc;
     make_cost_const<NS, NU>(env, cc);
-    const size_t lds =
-        (gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) + (size_t)SX_TILE * rp.H * NU) * sizeof(double);
-    if (int r = allow_lds(cem_rollout_kernel<NS, NU>, lds)) return r;
+    const size_t lds = (gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw, all_at_once ? NS : 1) +
+                        (size_t)SX_TILE * rp.H * NU) * sizeof(double);
     const int tiles = (rp.P + SX_TILE - 1) / SX_TILE;
-    hipLaunchKernelGGL((cem_rollout_kernel<NS, NU>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc,
-                       gc.stage_tab, rc, cc, rp);
+    if (all_at_once) {
+        if (int r = allow_lds(cem_rollout_kernel<NS, NU, false>, lds)) return r;
+        hipLaunchKernelGGL((cem_rollout_kernel<NS, NU, false>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc,
+                           gc.stage_tab, rc, cc, rp);
+    } else {
+        if (int r = allow_lds(cem_rollout_kernel<NS, NU, true>, lds)) return r;
+        hipLaunchKernelGGL((cem_rollout_kernel<NS, NU, true>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc,
+                           gc.stage_tab, rc, cc, rp);
+    }
     return check_launch();
 }
 
@@ -616,7 +626,8 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
     if (has_tab)
         hipLaunchKernelGGL(sx::build_stage_tab_kernel, dim3(1), dim3(64), 0, s,
                            reinterpret_cast<int4*>(const_cast<int32_t*>(model->stage_tab)), model->n_s, model->n_train,
-                           model->n_pad, SX_WAVES, sx::gp_stage_cap(model->n_s, model->n_pad, SX_WAVES));
+                           model->n_pad, SX_WAVES, sx::gp_stage_cap(model->n_s, model->n_pad, SX_WAVES),
+                           sx::gp_stage_cap(1, model->n_pad, SX_WAVES));
     return sx::check_launch();
 }
 
@@ -666,6 +677,7 @@ int sx_polytope_distance(const sx_env* env, int P, const double* p, const double
 int64_t sx_cem_rollout_workspace_bytes(const sx_gp_model* model, int E, int P, int H) {
     if (!model || E <= 0 || P <= 0 || H <= 0) return -1;
     if (sx::fused_fits(model->n_s, model->n_u, model->n_train, model->n_pad, H)) return 0;
+    if (model->n_s > 1 && sx::fused_fits(model->n_s, model->n_u, model->n_train, model->n_pad, H, 1)) return 0;
     return sx::big_ws_layout(nullptr, model->n_s, model->n_s + model->n_u, model->n_pad, (int64_t)E * P).total *
            (int64_t)sizeof(double);
 }

@@ -43,7 +43,11 @@ struct RolloutPtrs {
     int E, P, H;
 };
 
-template <int NS, int NU>
+// BYOUT = false: Kstar of all outputs in LDS at once -- two barriers per step (the kernel measured throughout DESIGN.md).
+// BYOUT = true: for training sets whose n_s Kstar buffers do not fit in LDS together, one output at a time
+// (Kstar_d | MFMA_d for d = 0 .. n_s - 1: 2 n_s barriers per step, per-output stage streams), still ONE launch for the
+// whole rollout and no Kstar in HBM.
+template <int NS, int NU, bool BYOUT = false>
 __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS, NS + NU> gc,
                                                                       const int4* __restrict__ stage_tab,
                                                                       ReachConst<NS, NU> rc,
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpTileLds<NS, D> lds;
     const int nw = blockDim.x >> 6;
-    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw);  // [16][H][NU]
+    double* acts = lds.carve(smem, gc.n_train, gc.n_pad, nw, BYOUT ? 1 : NS);  // [16][H][NU]
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int H = rp.H;
@@ -197,7 +201,9 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
     const unsigned long long ct0 = stamp();
 #endif
-    const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane);
+    // (in the output-by-output mode every phase fetches the head of its own stream)
+    const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane, gc.stage_cap);
+    const int4* __restrict__ const tab_one = stage_tab + (size_t)nw * (1 + gc.stage_cap);
     // Kstar shares (pairs of fragments).  Step 0: all waves alike.  From step 1 on wave 0 runs finish(); waves w and w + 4
     // share a SIMD, so wave 4 competes with finish() for its pipe and gets half a share (weight 1 against 2).
     int q0_begin, q0_end, q_begin = 0, q_end = 0;
@@ -212,15 +218,14 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 #ifdef SX_STAMPS
         const unsigned long long t0 = stamp();
 #endif
-        if (t > 0 && wave == 0) {
-            if (owner) finish(t - 1);
-        } else {
+        // the query point of this thread's particle (every thread of a Kstar wave; see next_centre above)
+        double zq[D];
+        const bool kstar_wave = !(t > 0 && wave == 0);
+        if (kstar_wave || BYOUT) {   // (output by output, wave 0 rejoins the Kstar waves after finish())
             const int c = lane & 15;
-            double zq[D];
             if (t == 0) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) zq[j] = zs_base[c * D + j];
-                gp_kstar_phase(gc, lds, q0_begin, q0_end, zq);
             } else {
                 double pc[NS];
                 next_centre(c, zs_base + ((t - 1) & 1) * 16 * D + c * D, pc);
@@ -228,8 +233,43 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
                 for (int i = 0; i < NS; ++i) zq[i] = pc[i];
 #pragma unroll
                 for (int cidx = 0; cidx < NU; ++cidx) zq[NS + cidx] = acts[(c * H + t) * NU + cidx];
-                gp_kstar_phase(gc, lds, q_begin, q_end, zq);
             }
+        }
+        if constexpr (BYOUT) {
+            // output by output; finish(t-1) rides on the first Kstar phase.  (z was derived above, before MFMA_0
+            // overwrites the means of the previous step.)
+            auto one_output = [&](auto dtag) {
+                constexpr int DD = decltype(dtag)::value;
+                if constexpr (DD < NS) {
+                    const int4* __restrict__ tab_d = tab_one + (size_t)DD * nw * (1 + gc.stage_cap_one);
+                    const MfmaHead head_d = gp_mfma_head(gc, tab_d, wave, nw, lane, gc.stage_cap_one);
+                    if (DD == 0 && t > 0) {
+                        if (wave == 0) {
+                            if (owner) finish(t - 1);
+                        } else {
+                            gp_kstar_phase_one<NS, D, DD>(gc, lds, q_begin, q_end, zq);
+                        }
+                    } else {
+                        gp_kstar_phase_one<NS, D, DD>(gc, lds, q0_begin, q0_end, zq);   // all waves, equal shares
+                    }
+                    __syncthreads();
+                    gp_mfma_phase<NS, D, 1>(gc, tab_d, lds, wave, nw, lane, head_d, gc.stage_cap_one, DD);
+                    __syncthreads();
+                }
+            };
+            one_output(std::integral_constant<int, 0>{});
+            one_output(std::integral_constant<int, 1>{});
+            one_output(std::integral_constant<int, 2>{});
+            one_output(std::integral_constant<int, 3>{});
+            static_assert(NS <= 4, "one_output is spelled out for up to four outputs");
+            continue;
+        }
+        if (!kstar_wave) {
+            if (owner) finish(t - 1);
+        } else if (t == 0) {
+            gp_kstar_phase(gc, lds, q0_begin, q0_end, zq);
+        } else {
+            gp_kstar_phase(gc, lds, q_begin, q_end, zq);
         }
 #ifdef SX_STAMPS
         const unsigned long long t1 = stamp();
@@ -238,7 +278,7 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
 #ifdef SX_STAMPS
         const unsigned long long t2 = stamp();
 #endif
-        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head);
+        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head, gc.stage_cap);
 #ifdef SX_STAMPS
         const unsigned long long t3 = stamp();
 #endif

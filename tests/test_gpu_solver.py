@@ -238,16 +238,23 @@ def test_cartpole_sized_rollout_vs_oracle():
     assert int(r['status'].item()) == 0 and ref.status == 0
 
 
-@pytest.mark.parametrize('which,n_train,P,H', [('pendulum', 700, 150, 5), ('cartpole', 330, 200, 4)])
-def test_large_training_set_path_vs_oracle(which, n_train, P, H):
-    """Training sets whose Kstar tile does not fit in LDS take the three-launch-per-step path (config 4's shape in
-    small): same numbers as the oracle, and the same numbers as the fused path on a problem both can run."""
+@pytest.mark.parametrize('which,n_train,P,H,path', [('pendulum', 700, 150, 5, 'by_output'), ('cartpole', 330, 200, 4, 'by_output'),
+                                                   ('cartpole', 800, 100, 4, 'by_output'), ('pendulum', 1100, 100, 4, 'big'),
+                                                   ('cartpole', 1010, 64, 3, 'big')])
+def test_large_training_set_path_vs_oracle(which, n_train, P, H, path):
+    """Training sets whose n_s Kstar buffers do not fit in LDS together: still one launch while ONE output's Kstar fits
+    (output-by-output mode of the fused kernel), the three-launch-per-step path beyond (config 4's shape in small).
+    Same numbers as the oracle either way."""
     import ctypes
     from safe_exploration_amd import _lib, problems
     from safe_exploration_amd.cem_mpc import cem_rollout
     spec = getattr(problems, which)(n_train=n_train, seed=5)
     ssm, env = problems.build(spec, DEV)
-    assert _lib.lib().sx_cem_rollout_workspace_bytes(ctypes.byref(ssm.device_model), 1, P, H) > 0   # really the big path
+    ws = _lib.lib().sx_cem_rollout_workspace_bytes(ctypes.byref(ssm.device_model), 1, P, H)
+    assert (ws > 0) == (path == 'big')   # the large-N path is the one that needs a workspace (Kstar in HBM)
+    small = getattr(problems, which)(n_train=200, seed=5)
+    ssm_small, _ = problems.build(small, DEV)
+    assert _lib.lib().sx_cem_rollout_workspace_bytes(ctypes.byref(ssm_small.device_model), 1, P, H) == 0
     gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
     rng = np.random.default_rng(3)
     acts = rng.normal(0, 0.4 if which == 'cartpole' else 0.15, size=(P, H, spec.n_u))

@@ -23,7 +23,8 @@ constexpr int kPredictThreads = 64 * SX_WAVES;
 // ---------------------------------------------------------------------------------------------------------------
 // sx_gp_predict: one 16-point tile per workgroup
 // ---------------------------------------------------------------------------------------------------------------
-template <int NS, int NU>
+// (BYOUT: one output's Kstar in LDS at a time, as in the rollout kernel)
+template <int NS, int NU, bool BYOUT = false>
 __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS, NS + NU> gc,
                                                                      const int4* __restrict__ stage_tab,
                                                                      const double* __restrict__ z, int P,
@@ -33,11 +34,12 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
     extern __shared__ __attribute__((aligned(16))) double smem[];
     GpTileLds<NS, D> lds;
     const int nw = blockDim.x >> 6;
-    lds.carve(smem, gc.n_train, gc.n_pad, nw);
+    lds.carve(smem, gc.n_train, gc.n_pad, nw, BYOUT ? 1 : NS);
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     gp_load_xs(gc, lds);
     const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane, gc.stage_cap);
+    const int4* __restrict__ const tab_one = stage_tab + (size_t)nw * (1 + gc.stage_cap);
     for (int tile = blockIdx.x; tile * SX_TILE < P; tile += gridDim.x) {
         const int g0 = tile * SX_TILE;
         if (tid < SX_TILE * D) {
@@ -50,10 +52,28 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
         double zq[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) zq[j] = lds.zs[(lane & 15) * D + j];
-        gp_kstar_phase(gc, lds, qb, qe, zq);
-        __syncthreads();
-        gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head, gc.stage_cap);
-        __syncthreads();
+        if constexpr (BYOUT) {
+            auto one_output = [&](auto dtag) {
+                constexpr int DD = decltype(dtag)::value;
+                if constexpr (DD < NS) {
+                    const int4* __restrict__ tab_d = tab_one + (size_t)DD * nw * (1 + gc.stage_cap_one);
+                    const MfmaHead head_d = gp_mfma_head(gc, tab_d, wave, nw, lane, gc.stage_cap_one);
+                    gp_kstar_phase_one<NS, D, DD>(gc, lds, qb, qe, zq);
+                    __syncthreads();
+                    gp_mfma_phase<NS, D, 1>(gc, tab_d, lds, wave, nw, lane, head_d, gc.stage_cap_one, DD);
+                    __syncthreads();
+                }
+            };
+            one_output(std::integral_constant<int, 0>{});
+            one_output(std::integral_constant<int, 1>{});
+            one_output(std::integral_constant<int, 2>{});
+            one_output(std::integral_constant<int, 3>{});
+        } else {
+            gp_kstar_phase(gc, lds, qb, qe, zq);
+            __syncthreads();
+            gp_mfma_phase(gc, stage_tab, lds, wave, nw, lane, head, gc.stage_cap);
+            __syncthreads();
+        }
         if (tid < SX_TILE && g0 + tid < P) {
             double zz[D], m[NS], v[NS], jc[NS][D];
 #pragma unroll
@@ -255,9 +275,9 @@ static int allow_lds(K kernel, size_t bytes) {
     return SX_OK;
 }
 
-static bool predict_fits(int ns, int nu, int n_train, int n_pad) {
+static bool predict_fits(int ns, int nu, int n_train, int n_pad, int ns_lds = -1) {
     const int nw = kPredictThreads / 64;
-    return gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw) * sizeof(double) <= kMaxLdsBytes && n_pad <= 1024;
+    return gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw, ns_lds) * sizeof(double) <= kMaxLdsBytes && n_pad <= 1024;
 }
 
 template <int NS, int NU>
@@ -267,16 +287,23 @@ static int launch_predict_big(const sx_gp_model* m, const double* z, int P, doub
 template <int NS, int NU>
 static int launch_predict(const sx_gp_model* m, const double* z, int P, double* mean, double* var, double* jac,
                           double* workspace, int64_t workspace_bytes, hipStream_t stream) {
-    if (!predict_fits(NS, NU, m->n_train, m->n_pad))
+    const bool all_at_once = predict_fits(NS, NU, m->n_train, m->n_pad);
+    if (!all_at_once && !(NS > 1 && predict_fits(NS, NU, m->n_train, m->n_pad, 1)))
         return launch_predict_big<NS, NU>(m, z, P, mean, var, jac, workspace, workspace_bytes, stream);
     const int nw = kPredictThreads / 64;
     auto gc = make_gp_const<NS, NU>(m, nw);
-    const size_t lds = gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw) * sizeof(double);
-    if (int rc = allow_lds(gp_predict_kernel<NS, NU>, lds)) return rc;
+    const size_t lds = gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw, all_at_once ? NS : 1) * sizeof(double);
     const int tiles = (P + SX_TILE - 1) / SX_TILE;
     const int grid = tiles < 4096 ? tiles : 4096;
-    hipLaunchKernelGGL((gp_predict_kernel<NS, NU>), dim3(grid), dim3(kPredictThreads), lds, stream, gc, gc.stage_tab, z, P,
-                       mean, var, jac);
+    if (all_at_once) {
+        if (int rc = allow_lds(gp_predict_kernel<NS, NU, false>, lds)) return rc;
+        hipLaunchKernelGGL((gp_predict_kernel<NS, NU, false>), dim3(grid), dim3(kPredictThreads), lds, stream, gc,
+                           gc.stage_tab, z, P, mean, var, jac);
+    } else {
+        if (int rc = allow_lds(gp_predict_kernel<NS, NU, true>, lds)) return rc;
+        hipLaunchKernelGGL((gp_predict_kernel<NS, NU, true>), dim3(grid), dim3(kPredictThreads), lds, stream, gc,
+                           gc.stage_tab, z, P, mean, var, jac);
+    }
     return check_launch();
 }
 
@@ -634,6 +661,7 @@ int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void
 int64_t sx_gp_predict_workspace_bytes(const sx_gp_model* model, int P) {
     if (!model || P < 0) return -1;
     if (sx::predict_fits(model->n_s, model->n_u, model->n_train, model->n_pad)) return 0;
+    if (model->n_s > 1 && sx::predict_fits(model->n_s, model->n_u, model->n_train, model->n_pad, 1)) return 0;
     return sx::big_ws_layout(nullptr, model->n_s, model->n_s + model->n_u, model->n_pad, P).total * (int64_t)sizeof(double);
 }
 

@@ -283,9 +283,10 @@ def test_large_training_set_path_vs_oracle(which, n_train, P, H, path):
         np.testing.assert_array_equal(r2['con_cost'][e].cpu().numpy(), ref_e.con_cost)
 
 
-def test_gp_predict_large_training_set_vs_oracle():
+@pytest.mark.parametrize('n_train', [650, 1100])   # output-by-output single launch / Kstar in HBM
+def test_gp_predict_large_training_set_vs_oracle(n_train):
     from safe_exploration_amd import problems
-    spec = problems.pendulum(n_train=650, seed=9)
+    spec = problems.pendulum(n_train=n_train, seed=9)
     ssm, _ = problems.build(spec, DEV)
     gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
     rng = np.random.default_rng(1)

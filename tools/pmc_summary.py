@@ -18,7 +18,8 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = {'cem_rollout_kernel<2,1>': 'cem_rollout_kernel<2, 1>', 'cem_rank_kernel<4>': 'cem_rank_kernel<4>'}
+# (needle: the all-outputs-at-once instantiation of the rollout kernel; its third template argument is BYOUT = false)
+KERNELS = {'cem_rollout_kernel<2,1>': 'cem_rollout_kernel<2, 1, false>', 'cem_rank_kernel<4>': 'cem_rank_kernel<4>'}
 
 
 def main(dirs):

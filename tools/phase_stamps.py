@@ -33,10 +33,10 @@ for _ in range(3):
     cem_rollout(ssm, env, x0, H, mean=mean, std=std, noise=noise)
 torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(nwg, nw, 8).astype(np.float64)
-s = raw[:, :, :6] / H
+s = raw[:, :, :4] / H   # (slots 4, 5: a third phase that no longer exists)
 clk = np.median(raw[:, 0, 6] / (raw[:, 0, 7] * 10.0))
 print(f'shader clock while the kernel runs: {clk:.2f} GHz (s_memtime cycles per s_memrealtime tick; all {nwg} workgroups resident)')
-names = ['kstar', 'kstar->barrier', 'mfma', 'mfma->barrier', 'epilogue', 'epilogue->barrier']
+names = ['kstar', 'kstar->barrier', 'mfma', 'mfma->barrier']
 print(f'cycles per step (median over {nwg} workgroups), per wave:')
 for w in range(nw):
     med = np.median(s[:, w, :], axis=0)

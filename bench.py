@@ -1,192 +1,314 @@
 #!/usr/bin/env python
-"""Headline benchmark: CEM particle-step evaluations/s of the fused safe-MPC solve (BASELINE.json configs[1]).
+"""Benchmark of the fused safe-MPC solve on the BASELINE.json workloads: CEM particle-step evaluations/s.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--config {1,2,3,4,5}] [--gpus N] [--steps K] [--warmup W] [--backend {nccl,gloo}]
 
-One STEP = one complete MPC solve (`get_action`'s optimiser call): `iters` CEM iterations, each = draw the action noise,
-roll all particles out for H steps (GP predict + one-step reachability + costs, one fused launch), rank, refit.
-Weak scaling: every GPU holds P particles (N GPUs optimise over N*P particles) and the ranks exchange their elite rows
-with ONE all-reduce per CEM iteration.  Inputs are synthetic (seeded) and resident in HBM before the timed region.
-Prints ONE JSON line on rank 0.
+`--config` picks a BASELINE.json workload by number (default 2, the one the metric is quoted on; the constants live in
+safe_exploration_amd/problems.py:baseline_workload).  `--gpus N` alone is enough: the parent process starts N fresh
+children (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, nothing touches the GPU before the spawn) and
+exits with the worst child's code; under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are already
+there and nothing is spawned.
+
+One STEP = one complete MPC solve (`get_action`'s optimiser call): `iterations` CEM iterations, each = draw the action
+noise, roll all particles out for H steps (GP predict + one-step reachability + costs), rank, refit.  Weak scaling:
+every GPU holds the workload's per-GPU particle count; configs 2-4 shard ONE problem's particles and exchange elite rows
+with ONE all-reduce per iteration, config 5 stripes independent episodes (no collective).  Inputs are synthetic (seeded)
+and resident in HBM before the timed region.  Rank 0 prints ONE JSON line; a non-zero device status (the reference would
+have raised ValueError on this workload) is an error, not a throughput.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+F64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; DESIGN.md "Roofline"
+MFMA_FLOPS = 2048               # one v_mfma_f64_16x16x4_f64 = 16 x 16 x 4 x 2 flop
+# the reference's own onestep_reachability on the build container's 8 cores, cfg-2 shape (327 ms per step of
+# 4096 particles; the reference cannot travel to the GPU box, so this number is quoted, not re-measured)
+REFERENCE_CPU = {'value': 1.25e4, 'unit': 'particle-steps/s', 'cores': 8, 'kind': 'reference',
+                 'sample': 'gp_reachability_pytorch.onestep_reachability, P=4096 N=200 f64, stand-in exact GP, torch-CPU, '
+                           'measured in the build container (SURVEY.md section 6), not on this box'}
+DEFAULT_STEPS = {1: (200, 20), 2: (100, 10), 3: (50, 5), 4: (3, 1), 5: (30, 3)}
+
+
 # algorithmic flops per particle-step  F = n_s [2N^2 + 2N + 2N + 2ND + 3ND + N]
 def algorithmic_flops_per_particle_step(n_s, n_train, d_in):
     return n_s * (2 * n_train ** 2 + 2 * n_train + 2 * n_train + 2 * n_train * d_in + 3 * n_train * d_in + n_train)
 
 
-F64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; DESIGN.md "Roofline"
+def n_pad_of(n_train, d_in):
+    return (n_train + 1 + d_in + 15) // 16 * 16          # csrc/sx_gp.hpp gp_n_pad
 
 
-def pmc_mfma_instructions(workload_key):
-    """v_mfma_f64_16x16x4 instructions per launch of the dominant kernel (SQ_INSTS_MFMA, same committed PMC passes), or
-    None: 2048 flop each -- what the kernel EXECUTES, as opposed to the algorithmic count the roofline contract uses."""
+def mfma_per_launch_fused(n_s, n_train, d_in, tiles, horizon, waves=8):
+    """v_mfma_f64_16x16x4 instructions one cem_rollout_kernel launch executes: per 16-particle tile and step, every
+    output's triangular product (row-block rb = 2 (rb + 1) fragment pairs = 4 (rb + 1) MFMAs) plus one column-total MFMA
+    per output and wave.  (rocprofv3's SQ_INSTS_MFMA agrees to the instruction: profiles/*pmc*.json.)"""
+    nrb = n_pad_of(n_train, d_in) // 16
+    per_tile_step = n_s * 2 * nrb * (nrb + 1) + waves * n_s
+    return per_tile_step * tiles * horizon
+
+
+def mfma_per_launch_trmm(n_s, n_train, d_in, particles):
+    """The same for ONE trmm_reduce_kernel launch (one step of the large-N path): 128 x 128 tiles, row-blocks beyond
+    their diagonal skipped (csrc/sx_big.hpp)."""
+    nrb = n_pad_of(n_train, d_in) // 16
+    p128 = (particles + 127) // 128
+    row_tiles = (nrb + 7) // 8
+    per_ptile = 0
+    for rt in range(row_tiles):
+        rb0, rb_end = rt * 8, min(rt * 8 + 8, nrb)
+        npairs = 2 * rb_end
+        for rb in range(rb0, rb0 + 8):
+            per_ptile += min(npairs, 2 * (rb + 1)) * 16      # 8 particle tiles x 2 MFMAs per (row-block, pair)
+    return per_ptile * p128 * n_s
+
+
+def pmc_summary(cfg):
+    """The committed rocprofv3 --pmc summary for this config (profiles/r02_pmc_cfg<N>.json), or None.  bench.py cannot
+    collect PMC counters itself; the numbers are only reported for the workload they were collected on."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
-            d = json.load(f)
-        if d.get('workload') == workload_key:
-            return d['per_launch_averages']['cem_rollout_kernel<2,1>']['SQ_INSTS_MFMA']
+        with open(os.path.join(ROOT, 'profiles', f'r02_pmc_cfg{cfg}.json')) as f:
+            return json.load(f)
     except Exception:
-        pass
-    return None
+        return None
 
 
-def pmc_traffic(workload_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), or None.
-    bench.py cannot collect PMC counters itself; the number is only reported for the workload it was collected on."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
-            d = json.load(f)
-        if d.get('workload') == workload_key:
-            return d['hbm_traffic_bytes_per_launch']['cem_rollout_kernel<2,1>']
-    except Exception:
-        pass
-    return None
-
-
-
-def cpu_baseline(spec, horizon, particles, elites, budget_s=12.0, max_iters=64):
+def cpu_baseline(w, budget_s=12.0):
     """The oracle's C restatement (oracle/csrc, OpenMP over particles; a port of the reference's arithmetic) on the host
-    cores, on a bounded sample of the same workload: whole CEM iterations until `budget_s` seconds are spent."""
+    cores, on a bounded sample of the same workload: chunks of particles of the first CEM iteration until `budget_s`
+    seconds are spent."""
     import numpy as np
     from oracle import c_oracle
     from oracle import cem as ocem
     from oracle.gp import ExactGP
     from safe_exploration_amd import problems
+    spec, H = w.spec, w.horizon
     gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
     prob = problems.oracle_problem(spec, ocem)
     rng = np.random.default_rng(1)
-    mean, std = np.zeros((horizon, spec.n_u)), np.full((horizon, spec.n_u), 0.1)
-    x0 = np.array([0.02, -0.03] + [0.0] * (spec.n_s - 2))[:spec.n_s]
-    c_oracle.rollout(prob, gp, x0, mean[None] + std[None] * rng.normal(size=(64, horizon, spec.n_u)), want_traj=False)
+    x0 = w.x0[0]
+    gp_mean = lambda x, u: gp.predict(np.concatenate((x, u))[None], jacobians=False)[0][0]
+    mean = problems.lqr_plan(spec, x0, H, gp_mean) if w.warm_start != 'zero' else np.zeros((H, spec.n_u))
+    std = np.broadcast_to(np.asarray(w.init_std, dtype=np.float64).reshape(-1, 1)[:H], (H, spec.n_u)) \
+        if np.ndim(w.init_std) else np.full((H, spec.n_u), float(w.init_std))
+    threads = c_oracle.max_threads()
+    c_oracle.rollout(prob, gp, x0, mean[None] + std[None] * rng.normal(size=(threads, H, spec.n_u)), want_traj=False)
+    # chunk size: enough particles to keep every thread busy, small enough that one chunk stays well inside the budget
+    chunk = max(threads * 4, min(w.particles, int(2e10 / (algorithmic_flops_per_particle_step(
+        spec.n_s, spec.X.shape[0], spec.n_s + spec.n_u) * H)) // threads * threads or threads))
     done, t0 = 0, time.perf_counter()
-    while done < max_iters and (time.perf_counter() - t0) < budget_s:
-        acts = mean[None] + std[None] * rng.normal(size=(particles, horizon, spec.n_u))
-        res = c_oracle.rollout(prob, gp, x0, acts, want_traj=False)
-        idx = ocem.rank(res.con_cost, res.obj_cost, elites)
-        mean, std = ocem.refit(acts[idx])
-        done += 1
+    while (time.perf_counter() - t0) < budget_s:
+        acts = mean[None] + std[None] * rng.normal(size=(chunk, H, spec.n_u))
+        c_oracle.rollout(prob, gp, x0, acts, want_traj=False)
+        done += chunk
     dt = time.perf_counter() - t0
-    return {'value': particles * horizon * done / dt, 'unit': 'particle-steps/s', 'cores': c_oracle.max_threads(),
-            'kind': 'port',
-            'sample': f'{done} CEM iteration(s) of the same workload ({particles} particles x H={horizon}), C oracle '
-                      f'(oracle/csrc, OpenMP, float64), {dt:.1f} s'}
+    return {'value': done * H / dt, 'unit': 'particle-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{done} particle rollouts (H={H}) of the same workload in chunks of {chunk}, C oracle (oracle/csrc, '
+                      f'OpenMP over particles, float64), {dt:.1f} s'}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """Parent of a plain `python bench.py --gpus N`: N fresh child processes, one per rank.  This process never touches
+    the GPU (no torch import before here), so the children are ordinary process starts, not an exec after HIP init."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f'bench.py: rank(s) failed: {bad}', file=sys.stderr)
+    return max(abs(c) for c in codes)
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--config', type=int, default=2, choices=[1, 2, 3, 4, 5], help='BASELINE.json config number')
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--particles', type=int, default=4096, help='per GPU')
-    ap.add_argument('--horizon', type=int, default=15)
-    ap.add_argument('--n-train', type=int, default=200)
-    ap.add_argument('--iters', type=int, default=8, help='CEM iterations per solve (reference default 8)')
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend for --gpus > 1 (nccl = RCCL; gloo lets several ranks share one card)')
+    ap.add_argument('--particles', type=int, default=0, help='per GPU; 0 = the workload\'s own')
+    ap.add_argument('--horizon', type=int, default=0)
+    ap.add_argument('--n-train', type=int, default=0)
+    ap.add_argument('--iters', type=int, default=0, help='CEM iterations per solve (reference default 8)')
     ap.add_argument('--elites', type=int, default=0, help='0 = 10 %% of the per-GPU particle count')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
-    from safe_exploration_amd import problems
+    from safe_exploration_amd import _lib, problems
     from safe_exploration_amd.cem_mpc import FusedCemMpc, fold_status
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: safe_exploration_amd has no CPU path')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    n_dev = torch.cuda.device_count()
+    dev = torch.device('cuda', local_rank % n_dev)    # (several ranks may share a card under --backend gloo)
+    torch.cuda.set_device(dev)
     group = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
         group = dist.group.WORLD
 
-    spec = problems.pendulum(n_train=args.n_train, seed=0)
-    ssm, env = problems.build(spec, dev)
-    P, H, iters = args.particles, args.horizon, args.iters
-    total_particles = P * world
-    # the elite count does not grow with the GPU count: every rank contributes its local top-k rows, so the per-iteration
-    # all-reduce stays at G x k x (2 + H n_u) doubles (445 KB at 8 GPUs) -- latency-bound on xGMI, as SURVEY 8e asks
+    w = problems.baseline_workload(args.config, n_gpus=world, n_train=args.n_train or None)
+    spec = w.spec
+    P = args.particles or w.particles
+    H = args.horizon or w.horizon
+    iters = args.iters or w.iterations
     elites = min(args.elites or max(1, P // 10), 2048)
-    mpc = FusedCemMpc(ssm, env, H, total_particles, elites, iters, device=dev, seed=1, init_std=0.1, process_group=group)
-    x0 = torch.tensor([[0.02, -0.03]], dtype=torch.float64, device=dev)
+    steps, warmup = DEFAULT_STEPS[w.cfg]
+    steps = args.steps if args.steps is not None else steps
+    warmup = args.warmup if args.warmup is not None else warmup
+    n_train, d_in = spec.X.shape[0], spec.n_s + spec.n_u
+    ssm, env = problems.build(spec, dev)
+    if w.sharded:
+        # ONE problem, particles sharded over the GPUs; the elite count does not grow with the GPU count: every rank
+        # contributes its local top-k rows, so the per-iteration all-reduce stays at G x k x (2 + H n_u) doubles
+        E, total_particles, solver_group = 1, P * world, group
+        x0 = torch.tensor(w.x0[:1], dtype=torch.float64, device=dev)
+    else:
+        # independent episodes striped over the GPUs ("replicas only"): no data-path collective
+        per_gpu = w.episodes // world
+        E, total_particles, solver_group = per_gpu, P, None
+        x0 = torch.tensor(w.x0[rank * per_gpu:(rank + 1) * per_gpu], dtype=torch.float64, device=dev)
+    init_std = w.init_std if np.ndim(w.init_std) == 0 else np.asarray(w.init_std)[:H]
+    mpc = FusedCemMpc(ssm, env, H, total_particles, elites, iters, device=dev, seed=1, init_std=init_std,
+                      warm_start='safe_policy' if w.warm_start != 'zero' else 'zero', process_group=solver_group)
 
     def barrier():
         if world > 1:
             dist.barrier(group)
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         mpc.solve(x0)
-    mpc.rollout_events = []
+    lib = _lib.lib()
+    _lib.check(lib.sx_profile_enable(max(4096, steps * iters * (3 * H + 4))), 'sx_profile_enable')
+    if world > 1 and w.sharded:
+        mpc.exchange_events = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         best, ok, _, status = mpc.solve(x0)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
     status_word = fold_status(status.cpu())
-    rollout_ms = [a.elapsed_time(b) for a, b in mpc.rollout_events]
-    mpc.rollout_events = None
-    avg_rollout_s = sum(rollout_ms) / len(rollout_ms) * 1e-3
+    kernels = _lib.profile_collect()                 # {kernel: (total ms, launches)}, HIP events on the launch stream
+    _lib.check(lib.sx_profile_disable(), 'sx_profile_disable')
+    exchange_us = None
+    if mpc.exchange_events:
+        xs = [a.elapsed_time(b) for a, b in mpc.exchange_events]
+        exchange_us = sum(xs) / len(xs) * 1e3
+    if world > 1 and not w.sharded:
+        sw = torch.tensor([status_word], dtype=torch.int32, device=dev if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(sw, op=dist.ReduceOp.MAX, group=group)    # (bit-OR would do; any non-zero word fails the run)
+        status_word = int(sw.item())
 
+    rc = 0
     if rank == 0:
-        particle_steps = total_particles * H * iters * args.steps
-        flops_unit = algorithmic_flops_per_particle_step(spec.n_s, args.n_train, spec.n_s + spec.n_u)
-        achieved = flops_unit * P * H / avg_rollout_s / 1e12
-        traffic = pmc_traffic(f'cfg2 pendulum N_train={args.n_train} H={H} P={P}')
-        n_mfma = pmc_mfma_instructions(f'cfg2 pendulum N_train={args.n_train} H={H} P={P}')
-        executed = (n_mfma * 2048 / avg_rollout_s / 1e12) if n_mfma else None
-        out = {
-            'metric': 'cem_particle_step_evals_per_s', 'value': particle_steps / elapsed, 'unit': 'particle-steps/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'cfg2 inverted pendulum n_s=2 n_u=1, exact GP N_train={args.n_train}, CEM H={H}, '
-                                   f'{P} particles/GPU, {iters} CEM iterations/solve, {elites} elites; 1 step = 1 MPC solve',
-                       'particles_per_gpu': P, 'horizon': H, 'n_train': args.n_train, 'cem_iterations': iters,
-                       'elites': elites, 'parallelism': f'particle-sharded x{world}, 1 all-reduce/iteration'},
-            'mpc_solves_per_s': args.steps / elapsed,
-            'particle_rollouts_per_s': total_particles * iters * args.steps / elapsed,
-            'device_status': status_word, 'solution_found': bool(ok[0].item()),
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / F64_MATRIX_PEAK_TFLOPS,
-                         'traffic': traffic,
-                         'traffic_unit': 'B/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.json)',
-                         'kernel': 'cem_rollout_kernel<2,1>',
-                         'avg_launch_us': avg_rollout_s * 1e6, 'launches_timed': len(rollout_ms),
-                         'hbm_gb_per_s': (traffic / avg_rollout_s / 1e9) if traffic else None,
-                         'hbm_frac_of_8TBps': (traffic / avg_rollout_s / 8e12) if traffic else None,
-                         'algorithmic_flops_per_launch': flops_unit * P * H,
-                         # the triangular form executes about half the algorithmic flops: the matrix pipe's real load
-                         'executed_tflops': executed,
-                         'executed_frac': (executed / F64_MATRIX_PEAK_TFLOPS) if executed else None},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(spec, H, P, max(1, P // 10))
-        print(json.dumps(out), flush=True)
+        if status_word != 0:
+            print(f'bench.py: device status {status_word} (SX_STATUS_* bits) on {w.name}: the reference would have raised '
+                  f'on this workload; no throughput reported', file=sys.stderr)
+            rc = 3
+        else:
+            episodes_total = E * (world if not w.sharded else 1)
+            particle_steps = (P * world if w.sharded else P * episodes_total) * H * iters * steps
+            flops_unit = algorithmic_flops_per_particle_step(spec.n_s, n_train, d_in)
+            per_kernel = {k: {'avg_launch_us': ms / n * 1e3, 'launches': n, 'share_of_step': ms / (elapsed * 1e3)}
+                          for k, (ms, n) in kernels.items()}
+            dominant = max(kernels, key=lambda k: kernels[k][0])
+            avg_s = kernels[dominant][0] / kernels[dominant][1] * 1e-3
+            if dominant == 'trmm_reduce_kernel':
+                units = E * P                                # particle-steps one launch processes (one step of all particles)
+                n_mfma = mfma_per_launch_trmm(spec.n_s, n_train, d_in, E * P)
+            else:
+                units = E * P * H                            # one launch = the whole rollout
+                n_mfma = mfma_per_launch_fused(spec.n_s, n_train, d_in, E * ((P + 15) // 16), H)
+            executed = n_mfma * MFMA_FLOPS / avg_s / 1e12
+            algorithmic = flops_unit * units / avg_s / 1e12
+            frac = executed / F64_MATRIX_PEAK_TFLOPS
+            assert frac <= 1.0, f'roofline fraction {frac} > 1: the flop count or the timer is wrong'
+            pmc = pmc_summary(w.cfg)
+            traffic = None
+            if pmc and pmc.get('workload') == f'cfg{w.cfg} N_train={n_train} H={H} P={P} E={E}':
+                traffic = pmc.get('hbm_traffic_bytes_per_launch', {}).get(dominant)
+            out = {
+                'metric': 'cem_particle_step_evals_per_s', 'value': particle_steps / elapsed, 'unit': 'particle-steps/s',
+                'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': f'{w.name}: n_s={spec.n_s} n_u={spec.n_u}, exact GP N_train={n_train}, CEM H={H}, '
+                                       f'{P} particles/GPU' + (f' x {E} episodes/GPU' if not w.sharded else '')
+                                       + f', {iters} CEM iterations/solve, {elites} elites; 1 step = 1 MPC solve'
+                                       + (f' ({w.notes})' if w.notes else ''),
+                           'baseline_config': w.cfg, 'particles_per_gpu': P, 'episodes_per_gpu': E, 'horizon': H,
+                           'n_train': n_train, 'cem_iterations': iters, 'elites': elites, 'warm_start': w.warm_start,
+                           'parallelism': (f'particle-sharded x{world}, 1 all-reduce/iteration' if w.sharded
+                                           else f'episodes striped x{world}, no collective'),
+                           'backend': args.backend if world > 1 else None},
+                'mpc_solves_per_s': steps * episodes_total / elapsed,
+                'particle_rollouts_per_s': particle_steps / H / elapsed,
+                'device_status': status_word, 'solution_found': bool(ok[0].item()),
+                'exchange_us': exchange_us,
+                'roofline': {'bound': 'mfma', 'achieved': executed, 'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': frac, 'kernel': dominant, 'avg_launch_us': avg_s * 1e6,
+                             'launches_timed': kernels[dominant][1],
+                             'flops': 'EXECUTED: v_mfma_f64_16x16x4 instructions per launch (analytic count of the '
+                                      'triangular form, equal to SQ_INSTS_MFMA) x 2048',
+                             'mfma_instructions_per_launch': n_mfma,
+                             'algorithmic_tflops': algorithmic,
+                             'algorithmic_flops_per_launch': flops_unit * units,
+                             'algorithmic_note': 'SURVEY 8d counts 2 N^2 per output for K* Kinv; the kernel evaluates '
+                                                 '||L^-1 k*||^2 (N^2), so algorithmic_tflops may exceed the peak',
+                             'traffic': traffic,
+                             'traffic_unit': 'B/launch (rocprofv3 FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md '
+                                             'prescribes; profiles/r02_pmc_cfg*.json)',
+                             'hbm_gb_per_s': (traffic / avg_s / 1e9) if traffic else None},
+                'kernels': per_kernel,
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline(w)
+                if w.cfg == 2:
+                    out['cpu_baseline']['reference_measured_elsewhere'] = REFERENCE_CPU
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(group)
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == '__main__':

@@ -91,6 +91,20 @@ typedef struct sx_env {
 /* Library / build identification: returns "sxamd <version> gfx950". */
 const char* sx_version(void);
 
+/* Optional kernel timer -- measurement support, not part of the reference's surface (it has no profiler: SURVEY.md 5).
+ * While enabled, every launch of the path's kernels is bracketed by a pair of HIP events on the stream the kernel is
+ * launched on (at most `max_launches` launches are recorded); sx_profile_collect synchronises those events and returns
+ * the summed elapsed time and the launch count of one kernel class.  bench.py's `roofline.avg_launch_us` comes from here. */
+#define SX_PROF_ROLLOUT_FUSED 0  /* cem_rollout_kernel            */
+#define SX_PROF_RANK 1           /* cem_rank_kernel               */
+#define SX_PROF_KSTAR_BIG 2      /* kstar_big_kernel   (large-N path) */
+#define SX_PROF_TRMM_BIG 3       /* trmm_reduce_kernel (large-N path) */
+#define SX_PROF_STEP_BIG 4       /* step_big_kernel    (large-N path) */
+#define SX_PROF_KINDS 5
+int sx_profile_enable(int max_launches);
+int sx_profile_collect(int kind, double* total_ms, int64_t* launches);
+int sx_profile_disable(void);
+
 #ifndef SX_WAVES
 #define SX_WAVES 8               /* waves per workgroup in the GP kernels (the stage table is laid out for it) */
 #endif
@@ -141,7 +155,10 @@ int64_t sx_gp_predict_workspace_bytes(const sx_gp_model* model, int P);
 /* One-step ellipsoidal reachability given the GP outputs at (p, u).
  * p dev [P x n_s]; Q dev [P x n_s x n_s] or NULL (point branch); u dev [P x n_u]; mean/var dev [P x n_s];
  * jac dev [P x n_s x D] (ignored in the point branch); outputs p1 dev [P x n_s], Q1 dev [P x n_s x n_s],
- * sigma dev [P x n_s] (the variance after the zero fix-up); status dev int32 (OR-ed).
+ * sigma dev [P x n_s] (the variance after the zero fix-up); status dev int32 (OR-ed; bit 16 is used as scratch during
+ * the call and is clear on return).
+ * The zero fix-up follows the reference's WHOLE-BATCH rule: an exact zero anywhere in `var` lifts every var <= 0 of the
+ * batch to 1e-5 (a one-workgroup pre-pass over `var` finds it); without one a negative variance ends as SX_STATUS_NAN.
  * Uses env->{a,b,k_fb,l_mu,l_sigma,beta}.
  * Replaces: onestep_reachability (gp_reachability_pytorch.py:18-181) with its helpers
  * compute_remainder_overapproximations_pytorch (utils.py:152-194), ellipsoid_from_rectangle_pytorch and

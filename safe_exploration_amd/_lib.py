@@ -16,6 +16,11 @@ SX_OK, SX_ERR_ARG, SX_ERR_UNSUPPORTED, SX_ERR_LAUNCH = 0, 1, 2, 3
 SX_STATUS_NAN, SX_STATUS_ZERO_FIX, SX_STATUS_UB_NONPOS, SX_STATUS_NOT_PD = 1, 2, 4, 8
 SX_OBJ_NEG_VARIANCE, SX_OBJ_AFFINE_ABS = 0, 1
 SX_CON_TERMINAL, SX_CON_ALL_STATES = 0, 1
+SX_PROF_ROLLOUT_FUSED, SX_PROF_RANK, SX_PROF_KSTAR_BIG, SX_PROF_TRMM_BIG, SX_PROF_STEP_BIG = range(5)
+PROF_KERNELS = {SX_PROF_ROLLOUT_FUSED: 'cem_rollout_kernel', SX_PROF_RANK: 'cem_rank_kernel',
+                SX_PROF_KSTAR_BIG: 'kstar_big_kernel', SX_PROF_TRMM_BIG: 'trmm_reduce_kernel',
+                SX_PROF_STEP_BIG: 'step_big_kernel'}
+SX_ACTION_VIOLATION_COST, SX_STATE_VIOLATION_COST = 3.0, 10.0
 
 _ERR = {SX_ERR_ARG: 'bad argument (null pointer, non-positive size or inconsistent shapes)',
         SX_ERR_UNSUPPORTED: 'unsupported dimension (n_s/n_u not instantiated, too many polytope rows, or the training '
@@ -57,6 +62,9 @@ SIGNATURES = {
     'sx_cem_rollout': (c_int, [POINTER(SxGpModel), POINTER(SxEnv), c_int, c_int, c_int] + [c_void_p] * 12
                        + [c_int64, c_void_p]),
     'sx_cem_rollout_workspace_bytes': (c_int64, [POINTER(SxGpModel), c_int, c_int, c_int]),
+    'sx_profile_enable': (c_int, [c_int]),
+    'sx_profile_collect': (c_int, [c_int, POINTER(c_double), POINTER(c_int64)]),
+    'sx_profile_disable': (c_int, []),
     'sx_cem_rank_refit': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64]
                           + [c_void_p] * 7),
 }
@@ -115,3 +123,14 @@ def fill(carray, values) -> None:
     assert len(flat) <= len(carray), (len(flat), len(carray))
     for i, v in enumerate(flat):
         carray[i] = float(v)
+
+
+def profile_collect() -> dict:
+    """{kernel name: (total ms, launches)} of the launches recorded since sx_profile_enable (synchronises them)."""
+    out = {}
+    for kind, name in PROF_KERNELS.items():
+        ms, n = c_double(), c_int64()
+        check(lib().sx_profile_collect(kind, ctypes.byref(ms), ctypes.byref(n)), 'sx_profile_collect')
+        if n.value:
+            out[name] = (ms.value, n.value)
+    return out

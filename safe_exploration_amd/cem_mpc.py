@@ -18,7 +18,7 @@ import torch
 from torch import Tensor
 
 from . import _lib, distributed
-from .gp_reachability_pytorch import raise_for_status
+from .gp_reachability_pytorch import raise_for_status, save_failure_state
 from .ssm_cem.gp_ssm_cem import GpCemSSM
 
 
@@ -70,6 +70,66 @@ def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, act
     return dict(actions=actions, obj_cost=obj, con_cost=con, traj=traj, sigma=sigma, status=status)
 
 
+def cem_rollout_stepwise(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, actions: Tensor, *, status: Tensor, group=None,
+                         objective_hook=None):
+    """The rollout of ONE problem step by step, the way the reference's optimiser drives it: H dynamics-callback calls on
+    the whole particle batch (safempc_cem.py:288-302), each = sx_gp_predict + sx_onestep_reach, then the costs.
+
+    This is the path that keeps the reference's WHOLE-BATCH zero fix-up (gp_reachability_pytorch.py:234-243: an exact
+    zero variance anywhere in the batch also lifts the negative ones), which the fused kernel cannot see across its
+    workgroups.  `FusedCemMpc` falls back to it when a fused solve reports both SX_STATUS_NAN and SX_STATUS_ZERO_FIX --
+    the only case in which the two rules can differ.  ~3 H launches per iteration instead of one; nothing synchronises.
+
+    x0 [n_s]; actions [P x H x n_u] (this rank's particles); with a process group the batch spans the ranks: the
+    "zero present" flag is all-reduced (MAX) per step.  Returns dict(obj_cost [P], con_cost [P]); `status` is OR-ed.
+    """
+    n_s, n_u = ssm.num_states, ssm.num_actions
+    dev = actions.device
+    P, H, _ = actions.shape
+    lib = _lib.lib()
+    arr = lambda field, r, c: torch.tensor(list(field)[:r * c], dtype=torch.float64, device=dev).view(r, c)
+    u_min, u_max = arr(env.u_min, 1, n_u), arr(env.u_max, 1, n_u)
+    w_abs, target, w_lin = arr(env.obj_w_abs, 1, n_s), arr(env.obj_target, 1, n_s), arr(env.obj_w_lin, 1, n_s)
+    p = x0.reshape(1, n_s).expand(P, n_s).contiguous()
+    q = None
+    obj = torch.zeros(P, dtype=torch.float64, device=dev)
+    con = torch.zeros(P, dtype=torch.float64, device=dev)
+    d = torch.empty((P, env.m), dtype=torch.float64, device=dev)
+    inside = torch.empty((P,), dtype=torch.uint8, device=dev)
+    for t in range(H):
+        u = actions[:, t].contiguous()
+        if q is None:
+            mean, var = ssm.predict_without_jacobians(p, u)
+            jac = None
+        else:
+            mean, var, jac = ssm.predict_with_jacobians(p, u)
+        if group is not None:
+            # the batch spans the ranks: if ANY rank holds an exact zero, every rank lifts its non-positive variances
+            zero_any = (var == 0).any().to(torch.int32).reshape(1)
+            torch.distributed.all_reduce(zero_any, op=torch.distributed.ReduceOp.MAX, group=group)
+            lifted = zero_any.bool() & (var <= 0)
+            status |= torch.where(lifted.any(), _lib.SX_STATUS_ZERO_FIX, 0).to(torch.int32)
+            var = torch.where(lifted, torch.full_like(var, 1e-5), var)
+        p1, q1, sigma = torch.empty_like(p), torch.empty((P, n_s, n_s), dtype=torch.float64, device=dev), torch.empty_like(p)
+        _lib.check(lib.sx_onestep_reach(ctypes.byref(env), P, _lib.ptr(p), _lib.ptr(q), _lib.ptr(u), _lib.ptr(mean),
+                                        _lib.ptr(var.contiguous()), _lib.ptr(jac), _lib.ptr(p1), _lib.ptr(q1),
+                                        _lib.ptr(sigma), _lib.ptr(status), _lib.stream_ptr(dev)), 'sx_onestep_reach')
+        # costs: objective safempc_cem.py:304-312, action box test_safempc_cem.py:59-71, polytope safempc_cem.py:102-132
+        if objective_hook is not None:
+            obj = obj + objective_hook(p1)
+        elif env.obj_mode == _lib.SX_OBJ_NEG_VARIANCE:
+            obj = obj - sigma.sum(dim=1)
+        else:
+            obj = obj + (w_abs * (target - p1).abs() + w_lin * p1).sum(dim=1)
+        con = con + _lib.SX_ACTION_VIOLATION_COST * ((u < u_min) | (u > u_max)).any(dim=1)
+        if env.con_mode == _lib.SX_CON_ALL_STATES or t == H - 1:
+            _lib.check(lib.sx_polytope_distance(ctypes.byref(env), P, _lib.ptr(p1), _lib.ptr(q1), 1.0, _lib.ptr(d),
+                                                _lib.ptr(inside), _lib.stream_ptr(dev)), 'sx_polytope_distance')
+            con = con + _lib.SX_STATE_VIOLATION_COST * (inside == 0)
+        p, q = p1, q1
+    return dict(obj_cost=obj, con_cost=con)
+
+
 def cem_rank_refit(con: Tensor, obj: Tensor, actions: Tensor, k: int, *, cost_stride: int = 1,
                    act_stride: Optional[int] = None, row_len: Optional[int] = None, num_candidates: Optional[int] = None,
                    num_problems: Optional[int] = None, want_rows: bool = False, want_refit: bool = True,
@@ -105,6 +165,11 @@ def cem_rank_refit(con: Tensor, obj: Tensor, actions: Tensor, k: int, *, cost_st
     return dict(elite_idx=idx, elite_rows=rows, mean=mean, std=std, best=best, best_ok=best_ok)
 
 
+# limits of cem_rank_kernel (csrc/sx_rank.hpp: kRankThreads * kRankSlots candidates per problem, kRankMaxK elites)
+RANK_MAX_CANDIDATES = 16384
+RANK_MAX_ELITES = 2048
+
+
 def fold_status(words) -> int:
     """Bitwise OR of the per-rank status words `solve` returns (host side: a handful of ints)."""
     out = 0
@@ -122,30 +187,54 @@ class FusedCemMpc:
     """
 
     def __init__(self, ssm: GpCemSSM, env: _lib.SxEnv, time_horizon: int, num_rollouts: int, num_elites: int,
-                 num_iterations: int, *, device=None, seed: int = 0, init_std: float = 1.0,
+                 num_iterations: int, *, device=None, seed: int = 0, init_std=1.0, warm_start: str = 'zero',
                  record_rollouts: bool = False, process_group=None):
         self._ssm = ssm
         self._env = env
         self._horizon = time_horizon
         self._num_iterations = num_iterations
         self._record = record_rollouts
-        self._init_std = float(init_std)
+        # the first iteration's sampling distribution: std is a scalar or one value per step [H] / [H x n_u];
+        # warm_start 'zero' = mean 0 (the reference's cold start), 'safe_policy' = the safe controller u = k_fb x rolled
+        # through the model's mean dynamics from x0 (safe_policy_plan)
+        self._init_std = torch.as_tensor(init_std, dtype=torch.float64).cpu()
+        if self._init_std.dim() > 0:
+            self._init_std = self._init_std.reshape(time_horizon, -1).expand(time_horizon, ssm.num_actions).clone()
+        if warm_start not in ('zero', 'safe_policy'):
+            raise ValueError(f"warm_start must be 'zero' or 'safe_policy', got {warm_start!r}")
+        self._warm_start = warm_start
         self._group = process_group
         self._world, self._rank = distributed.world_and_rank(process_group)
         self._num_rollouts = num_rollouts
         self._local_rollouts, _ = distributed.shard_particles(num_rollouts, self._world, self._rank)
         if num_elites > num_rollouts:
             raise ValueError(f'num_elites={num_elites} exceeds num_rollouts={num_rollouts}')
+        if num_elites > num_rollouts // self._world:
+            # every rank hands in its local top-k rows; a rank that owns fewer than k particles could not, and the
+            # global top-k would silently miss candidates
+            raise ValueError(f'num_elites={num_elites} exceeds the smallest per-GPU share '
+                             f'({num_rollouts // self._world} of {num_rollouts} particles over {self._world} GPUs)')
         self._num_elites = num_elites
-        self._local_elites = min(num_elites, num_rollouts // self._world)  # same k on every rank
+        self._local_elites = num_elites     # the same k on every rank
+        for what, count in (('particles per GPU', self._local_rollouts + (1 if num_rollouts % self._world else 0)),
+                            ('candidates after the exchange', self._world * num_elites if self._world > 1 else 0)):
+            if count > RANK_MAX_CANDIDATES:
+                raise ValueError(f'{count} {what} exceed the ranking kernel\'s limit of {RANK_MAX_CANDIDATES}')
+        if num_elites > RANK_MAX_ELITES:
+            raise ValueError(f'num_elites={num_elites} exceeds the ranking kernel\'s limit of {RANK_MAX_ELITES}')
         self._device = torch.device(device if device is not None else 'cuda:0')
+        self._init_std = self._init_std.to(self._device)
         self._gen = torch.Generator(device=self._device)
         self._gen.manual_seed(distributed.rank_seed(seed, self._rank))
         self.last_status = 0
+        self.stepwise_fallbacks = 0     # solves repeated through the step-by-step path (see _solve_checked)
+        self._last_noise = self._last_actions = None
         self._objective_hook = None
         # bench.py sets this to a list: (start, end) torch.cuda.Event pairs are then recorded around every
         # sx_cem_rollout launch, on the stream the kernel runs on
         self.rollout_events = None
+        # likewise around the multi-GPU part of an iteration (collective + global ranking launch): bench.py's exchange_us
+        self.exchange_events = None
 
     @property
     def num_iterations(self) -> int:
@@ -157,14 +246,43 @@ class FusedCemMpc:
         on the recorded trajectory centres, H small launches per iteration instead of none."""
         self._env = env
         self._objective_hook = objective_hook
+        self._prior_tensors = None
+
+    def _prior(self):
+        """(a [n_s x n_s], b [n_s x n_u], k_fb [n_u x n_s]) of the current sx_env as device tensors."""
+        if getattr(self, '_prior_tensors', None) is None:
+            n_s, n_u = self._ssm.num_states, self._ssm.num_actions
+            t = lambda arr, r, c: torch.tensor(list(arr)[:r * c], dtype=torch.float64, device=self._device).view(r, c)
+            self._prior_tensors = (t(self._env.a, n_s, n_s), t(self._env.b, n_s, n_u), t(self._env.k_fb, n_u, n_s))
+        return self._prior_tensors
+
+    def safe_policy_plan(self, x0: Tensor) -> Tensor:
+        """[E x H x n_u]: the safe controller u_t = k_fb x_t (reference safempc_cem.py:259-262, the last rung of the
+        fallback ladder) rolled through the model's MEAN dynamics x_{t+1} = a x_t + b u_t + mu(x_t, u_t) from x0
+        [E x n_s] -- H one-point-per-episode sx_gp_predict launches, nothing synchronises.  It is the warm start of
+        workloads whose open-loop instability (cart-pole: 1.77 per step, 9e4 over H = 20) leaves a zero-mean start no
+        feasible particle to learn from."""
+        a, b, k_fb = self._prior()
+        x = x0.to(self._device, torch.float64)
+        plan = []
+        for _ in range(self._horizon):
+            u = x @ k_fb.t()
+            mean, _ = self._ssm.predict_without_jacobians(x.contiguous(), u.contiguous())
+            plan.append(u)
+            x = x @ a.t() + u @ b.t() + mean
+        return torch.stack(plan, dim=1)
 
     def sample_noise(self, episodes: int = 1) -> Tensor:
         return torch.randn((episodes, self._local_rollouts, self._horizon, self._ssm.num_actions), dtype=torch.float64,
                            device=self._device, generator=self._gen)
 
     def solve(self, x0: Tensor, noise: Optional[Tensor] = None, init_mean: Optional[Tensor] = None,
-              init_std: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, List[Rollouts], Tensor]:
+              init_std: Optional[Tensor] = None, stepwise: bool = False) -> Tuple[Tensor, Tensor, List[Rollouts], Tensor]:
         """E independent solves from x0 [E x n_s] (points).  Nothing here synchronises with the host.
+
+        stepwise: roll out through `cem_rollout_stepwise` (H x (sx_gp_predict + sx_onestep_reach) per iteration, the
+        reference's whole-batch zero fix-up) instead of the fused kernel; `get_actions` uses it to settle the one case
+        in which the fused kernel's per-particle fix-up can differ from the reference's.
 
         noise: optional [iters x E x P_local x H x n_u] pre-drawn standard normals (parity tests inject them).
         Returns (best [E x H x n_u], best_ok int32 [E], rollouts per iteration (if recorded), status int32 [G]: the
@@ -174,27 +292,44 @@ class FusedCemMpc:
         E = x0.size(0)
         dev = x0.device
         L = H * n_u
-        mean = torch.zeros((E, H, n_u), dtype=torch.float64, device=dev) if init_mean is None \
-            else init_mean.to(dev).reshape(E, H, n_u).clone()
-        std = torch.full((E, H, n_u), self._init_std, dtype=torch.float64, device=dev) if init_std is None \
-            else init_std.to(dev).reshape(E, H, n_u).clone()
+        if init_mean is not None:
+            mean = init_mean.to(dev).reshape(E, H, n_u).clone()
+        elif self._warm_start == 'safe_policy':
+            mean = self.safe_policy_plan(x0).contiguous()
+        else:
+            mean = torch.zeros((E, H, n_u), dtype=torch.float64, device=dev)
+        if init_std is not None:
+            std = init_std.to(dev).reshape(E, H, n_u).clone()
+        else:
+            std = self._init_std.to(dev).expand(E, H, n_u).contiguous()   # (already there: no copy)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         history: List[Rollouts] = []
         out = None
-        xbuf = None
+        xch = None
         if noise is None and 'sample_noise' not in vars(self):
             # one generator launch for the whole solve instead of one per iteration (a test that patches sample_noise
             # on the instance still gets its per-iteration calls)
             noise = torch.randn((self._num_iterations, E, self._local_rollouts, H, n_u), dtype=torch.float64,
                                 device=self._device, generator=self._gen)
+        self._last_noise, self._last_actions = noise, None
         for it in range(self._num_iterations):
             eps = noise[it] if noise is not None else self.sample_noise(E)
+            if noise is None:
+                self._last_noise = None      # per-iteration draws (a patched sample_noise): nothing to replay
             if self.rollout_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(torch.cuda.current_stream(dev))
-            r = cem_rollout(self._ssm, self._env, x0, H, mean=mean, std=std, noise=eps.contiguous(),
-                            want_traj=self._record or self._objective_hook is not None, status=status)
-            if self._objective_hook is not None:
+            if stepwise:
+                acts = (mean.unsqueeze(1) + std.unsqueeze(1) * eps).contiguous()       # [E x P x H x n_u]
+                per_e = [cem_rollout_stepwise(self._ssm, self._env, x0[e], acts[e], status=status,
+                                              group=self._group if self._world > 1 else None,
+                                              objective_hook=self._objective_hook) for e in range(E)]
+                r = dict(actions=acts, traj=None, obj_cost=torch.stack([q['obj_cost'] for q in per_e]),
+                         con_cost=torch.stack([q['con_cost'] for q in per_e]))
+            else:
+                r = cem_rollout(self._ssm, self._env, x0, H, mean=mean, std=std, noise=eps.contiguous(),
+                                want_traj=self._record or self._objective_hook is not None, status=status)
+            if self._objective_hook is not None and not stepwise:
                 n_s = self._ssm.num_states
                 centres = r['traj'][..., :n_s]                                   # [E x P x H x n_s]
                 obj = torch.zeros_like(r['obj_cost'])
@@ -208,34 +343,56 @@ class FusedCemMpc:
                 out = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites)
             else:
                 k = self._local_elites
-                G, n_slots = self._world, E * self._world * k * (2 + L)
-                if xbuf is None:
-                    # the zero-padded exchange buffers of ALL iterations in one allocation (one memset per solve); each
-                    # carries G extra cells behind the slots: the status words ride along with the last exchange
-                    xbuf = torch.zeros((self._num_iterations, n_slots + G), dtype=torch.float64, device=dev)
-                slots = xbuf[it, :n_slots].view(E, G, k, 2 + L)
+                if xch is None:
+                    xch = distributed.EliteExchange(self._num_iterations, E, k, L, self._group, dev)
                 if E == 1:
                     # the local elite rows go straight into this rank's slot: no copy between the kernel and the collective
                     cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_refit=False,
-                                   rows_out=slots[:, self._rank])
+                                   rows_out=xch.local_slot(it))
                 else:
                     local = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_rows=True, want_refit=False)
-                    slots[:, self._rank] = local['elite_rows']
+                    xch.local_slot(it).copy_(local['elite_rows'])
                 last = it == self._num_iterations - 1
+                if self.exchange_events is not None:
+                    xev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    xev[0].record(torch.cuda.current_stream(dev))
+                # the ONE collective of the iteration; on the last one the status words of all ranks ride along
+                # (every rollout of this solve has been enqueued by then)
+                cand, words = xch.exchange(it, status if last else None)
                 if last:
-                    xbuf[it, n_slots + self._rank] = status[0]      # every rollout of this solve has been enqueued
-                distributed.all_reduce_sum_(xbuf[it], self._group)               # the ONE collective of the iteration
-                if last:
-                    # every rank now holds the status words of all ranks: callers OR them, so all ranks raise together
-                    status = xbuf[it, n_slots:].to(torch.int32)
-                flat = slots.view(-1)
+                    status = words
+                flat = cand.reshape(-1)
                 out = cem_rank_refit(flat, flat[1:], flat[2:], self._num_elites, cost_stride=2 + L,
-                                     act_stride=2 + L, row_len=L, num_candidates=G * k, num_problems=E)
+                                     act_stride=2 + L, row_len=L, num_candidates=self._world * k, num_problems=E)
+                if self.exchange_events is not None:
+                    xev[1].record(torch.cuda.current_stream(dev))
+                    self.exchange_events.append(xev)
             mean, std = out['mean'].view(E, H, n_u), out['std'].view(E, H, n_u)
-            if self._record:
+            self._last_actions = r['actions']
+            if self._record and r['traj'] is not None:
                 for e in range(E):
                     history.append(Rollouts(r['traj'][e], r['actions'][e], r['obj_cost'][e], r['con_cost'][e]))
         return out['best'].view(E, H, n_u), out['best_ok'], history, status
+
+    def _solve_checked(self, x0: Tensor, where: str):
+        """`solve` + the one device->host hand-off of a solve (status words + feasibility flags) + the reference's
+        failure behaviour.  Returns (best [E x H x n_u], found bool [E] on the host, rollouts)."""
+        best, best_ok, history, status = self.solve(x0)
+        flags = torch.cat((status, best_ok)).cpu()
+        self.last_status = fold_status(flags[:status.numel()])
+        both = _lib.SX_STATUS_NAN | _lib.SX_STATUS_ZERO_FIX
+        if (self.last_status & both) == both and self._last_noise is not None:
+            # The fused kernel lifts exact-zero variances per particle; the reference decides on the whole batch: with a
+            # zero present it lifts the NEGATIVE variances too and carries on, where the kernel went to sqrt -> NaN
+            # (gp_reachability_pytorch.py:234-243).  Both bits set is the only case in which that can matter: repeat
+            # the solve with the same draws through the step-by-step path, which follows the reference's rule.
+            self.stepwise_fallbacks += 1
+            best, best_ok, history, status = self.solve(x0, noise=self._last_noise, stepwise=True)
+            flags = torch.cat((status, best_ok)).cpu()
+            self.last_status = fold_status(flags[:status.numel()])
+        raise_for_status(self.last_status, where,
+                         dump=lambda: save_failure_state(self._ssm, x0, self._last_actions))
+        return best, flags[status.numel():] != 0, history
 
     def get_actions_batch(self, states: Tensor) -> Tuple[Tensor, Tensor, List[Rollouts]]:
         """E independent episodes at once (BASELINE config 5): flat start states [E x (n_s + n_s^2)], all
@@ -250,11 +407,7 @@ class FusedCemMpc:
         if bool((states[:, n_s:] != 0).any()):
             raise NotImplementedError('get_actions_batch starts from point states (all-zero Q), as CemSafeMPC.get_action does')
         x0 = states[:, :n_s].to(self._device, torch.float64).contiguous()
-        best, best_ok, history, status = self.solve(x0)
-        flags = torch.cat((status, best_ok)).cpu()   # the one device->host hand-off of the batch
-        self.last_status = fold_status(flags[:status.numel()])
-        raise_for_status(self.last_status, 'get_actions_batch')
-        return best, flags[status.numel():] != 0, history
+        return self._solve_checked(x0, 'get_actions_batch')
 
     def get_actions(self, state: Tensor) -> Tuple[Optional[Tensor], List[Rollouts]]:
         """state: the flat start state [1 x (n_s + n_s^2)] with an all-zero Q block (a point, safempc_cem.py:234-235)."""
@@ -265,11 +418,7 @@ class FusedCemMpc:
         if bool((flat[:, n_s:] != 0).any()):
             raise NotImplementedError('get_actions starts from a point state (all-zero Q), as CemSafeMPC.get_action does')
         x0 = flat[:, :n_s].to(self._device, torch.float64).contiguous()
-        best, best_ok, history, status = self.solve(x0)
-        # the one device->host hand-off of a solve: status word + feasibility flag (+ the actions)
-        flags = torch.cat((status, best_ok)).cpu()
-        self.last_status = fold_status(flags[:status.numel()])
-        raise_for_status(self.last_status, 'get_actions')
-        if int(flags[status.numel()]) == 0:
+        best, found, history = self._solve_checked(x0, 'get_actions')
+        if not bool(found[0]):
             return None, history
         return best[0], history

@@ -4,6 +4,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "../../include/sx_amd.h"
 #include "sx_gp.hpp"
@@ -101,6 +105,20 @@ __global__ __launch_bounds__(kPredictThreads) void gp_predict_kernel(GpConst<NS,
 // ---------------------------------------------------------------------------------------------------------------
 // sx_onestep_reach / sx_polytope_distance: one particle per lane
 // ---------------------------------------------------------------------------------------------------------------
+// Pre-pass of sx_onestep_reach: does the variance batch hold an exact zero (gp_reachability_pytorch.py:238)?  ONE
+// workgroup, so it is the only writer of the scratch bit: it clears the bit a previous call may have left and sets it
+// again if this batch has a zero.  The main kernel reads the bit; both run on the caller's stream, in order.
+constexpr int kStatusScratchBatchZero = 0x10000;
+__global__ __launch_bounds__(1024) void batch_zero_flag_kernel(const double* __restrict__ var, int64_t n, int* __restrict__ status) {
+    int any = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) any |= (var[i] == 0.0) ? 1 : 0;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) {
+        atomicAnd(status, ~kStatusScratchBatchZero);
+        if (any) atomicOr(status, kStatusScratchBatchZero);
+    }
+}
+
 template <int NS, int NU>
 __global__ void onestep_reach_kernel(ReachConst<NS, NU> rc, int P, const double* __restrict__ p_in,
                                      const double* __restrict__ q_in, const double* __restrict__ u_in,
@@ -112,6 +130,8 @@ __global__ void onestep_reach_kernel(ReachConst<NS, NU> rc, int P, const double*
     if (g >= P) return;
     double p[NS], u[NU], mean[NS], var[NS], p1[NS], Q1[NS][NS];
     int st = 0;
+    // the whole-batch rule of _fix_zeros_nans: with an exact zero anywhere in the batch, every var <= 0 is lifted
+    const bool batch_zero = (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusScratchBatchZero) != 0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         p[i] = p_in[g * NS + i];
@@ -121,7 +141,7 @@ __global__ void onestep_reach_kernel(ReachConst<NS, NU> rc, int P, const double*
 #pragma unroll
     for (int c = 0; c < NU; ++c) u[c] = u_in[g * NU + c];
     if (q_in == nullptr) {
-        reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st);
+        reach_point<NS, NU>(rc, p, u, mean, var, p1, Q1, st, batch_zero);
     } else {
         double Q[NS][NS], jac[NS][D];
 #pragma unroll
@@ -131,7 +151,7 @@ __global__ void onestep_reach_kernel(ReachConst<NS, NU> rc, int P, const double*
 #pragma unroll
             for (int j = 0; j < D; ++j) jac[i][j] = jac_in[(g * NS + i) * D + j];
         }
-        reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st);
+        reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st, batch_zero);
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -252,6 +272,49 @@ static void make_cost_const(const sx_env* env, CostConst<SX_MAX_M, NS, NU>& cc) 
     cc.con_mode = env->con_mode;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Optional kernel timer (sx_profile_*): while enabled, every launch of the path's kernels is bracketed by a pair of
+// HIP events on the stream the kernel is launched on; sx_profile_collect adds the elapsed times up per kernel class.
+// This is how bench.py measures `roofline.avg_launch_us` live, inside its timed region.
+// ---------------------------------------------------------------------------------------------------------------
+struct ProfEntry {
+    int kind;
+    hipEvent_t start, stop;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static size_t g_prof_cap = 0;
+static std::vector<ProfEntry> g_prof_entries;
+static std::vector<hipEvent_t> g_prof_pool;
+
+struct ProfScope {
+    hipStream_t stream;
+    hipEvent_t stop = nullptr;
+    ProfScope(int kind, hipStream_t s) : stream(s) {
+        if (!g_prof_on) return;   // (read without the lock: enabling mid-launch only loses that launch)
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (!g_prof_on || g_prof_entries.size() >= g_prof_cap) return;
+        auto take = [&]() {
+            hipEvent_t e = nullptr;
+            if (!g_prof_pool.empty()) {
+                e = g_prof_pool.back();
+                g_prof_pool.pop_back();
+            } else if (hipEventCreate(&e) != hipSuccess) {
+                e = nullptr;
+            }
+            return e;
+        };
+        hipEvent_t a = take(), b = take();
+        if (!a || !b) return;
+        (void)hipEventRecord(a, stream);
+        g_prof_entries.push_back(ProfEntry{kind, a, b});
+        stop = b;
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, stream);
+    }
+};
+
 static int check_launch() {
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
@@ -262,15 +325,25 @@ static int check_launch() {
 }
 
 
+// Kernels that need more than 64 KB of dynamic LDS must be granted it once per (device, kernel); the grant is remembered,
+// so the hot loop's launches make no runtime call besides the launch itself.
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
     if (bytes > kMaxLdsBytes) return SX_ERR_UNSUPPORTED;
     if (bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)bytes) != hipSuccess) {
+        static std::mutex mu;
+        static std::map<std::pair<int, const void*>, size_t> granted;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const auto key = std::make_pair(dev, reinterpret_cast<const void*>(kernel));
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = granted.find(key);
+        if (it != granted.end() && it->second >= bytes) return SX_OK;
+        if (hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
             (void)hipGetLastError();
             return SX_ERR_UNSUPPORTED;
         }
+        granted[key] = bytes;
     }
     return SX_OK;
 }
@@ -314,8 +387,10 @@ static int launch_reach(const sx_env* env, int P, const double* p, const double*
     ReachConst<NS, NU> rc;
     if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
     const int threads = 64;
+    hipLaunchKernelGGL(batch_zero_flag_kernel, dim3(1), dim3(1024), 0, stream, var, (int64_t)P * NS, status);
     hipLaunchKernelGGL((onestep_reach_kernel<NS, NU>), dim3((P + threads - 1) / threads), dim3(threads), 0, stream, rc,
                        P, p, Q, u, mean, var, jac, p1, Q1, sigma, status);
+    hipLaunchKernelGGL(batch_zero_flag_kernel, dim3(1), dim3(64), 0, stream, var, (int64_t)0, status);  // clears the scratch bit
     return check_launch();
 }
 
@@ -411,12 +486,19 @@ static int launch_rollout_big(const sx_gp_model* m, const sx_env* env, const Rol
     hipLaunchKernelGGL((init_big_kernel<NS, NU>), dim3((unsigned)((p128 + 255) / 256)), dim3(256), 0, stream, bi, ws, total,
                        p128);
     for (int t = 0; t < rp.H; ++t) {
-        hipLaunchKernelGGL((kstar_big_kernel<NS, D>), dim3((unsigned)(p128 / 16), (unsigned)((m->n_pad + 255) / 256)),
-                           dim3(256), 0, stream, gc, ws);
-        hipLaunchKernelGGL((trmm_reduce_kernel<NS, D>), dim3((unsigned)(p128 / kBigTile), (unsigned)row_tiles, NS),
-                           dim3(kBigThreads), 0, stream, gc, ws, p128);
+        {
+            ProfScope prof(SX_PROF_KSTAR_BIG, stream);
+            hipLaunchKernelGGL((kstar_big_kernel<NS, D>), dim3((unsigned)(p128 / 16), (unsigned)((m->n_pad + 255) / 256)),
+                               dim3(256), 0, stream, gc, ws);
+        }
+        {
+            ProfScope prof(SX_PROF_TRMM_BIG, stream);
+            hipLaunchKernelGGL((trmm_reduce_kernel<NS, D>), dim3((unsigned)(p128 / kBigTile), (unsigned)row_tiles, NS),
+                               dim3(kBigThreads), 0, stream, gc, ws, p128);
+        }
         BigStep bs{rp.actions, rp.traj, rp.sigma, rp.obj_cost, rp.con_cost, rp.status, rp.H, t, row_tiles * 2,
                    (t > 0 || rp.q0 != nullptr) ? 1 : 0};
+        ProfScope prof(SX_PROF_STEP_BIG, stream);
         hipLaunchKernelGGL((step_big_kernel<NS, NU>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0, stream, gc, rc, cc, bs,
                            ws, total, p128);
     }
@@ -438,6 +520,7 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
     const size_t lds = (gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw, all_at_once ? NS : 1) +
                         (size_t)SX_TILE * rp.H * NU) * sizeof(double);
     const int tiles = (rp.P + SX_TILE - 1) / SX_TILE;
+    ProfScope prof(SX_PROF_ROLLOUT_FUSED, stream);
     if (all_at_once) {
         if (int r = allow_lds(cem_rollout_kernel<NS, NU, false>, lds)) return r;
         hipLaunchKernelGGL((cem_rollout_kernel<NS, NU, false>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc,
@@ -474,7 +557,51 @@ int sx_debug_set_stamps(unsigned long long* dev_buf) {
 }
 #endif
 
-const char* sx_version(void) { return "sxamd 0.1 gfx950"; }
+const char* sx_version(void) { return "sxamd 0.2 gfx950"; }
+
+int sx_profile_enable(int max_launches) {
+    if (max_launches <= 0) return SX_ERR_ARG;
+    std::lock_guard<std::mutex> lock(sx::g_prof_mu);
+    for (auto& e : sx::g_prof_entries) {
+        sx::g_prof_pool.push_back(e.start);
+        sx::g_prof_pool.push_back(e.stop);
+    }
+    sx::g_prof_entries.clear();
+    sx::g_prof_cap = (size_t)max_launches;
+    sx::g_prof_on = true;
+    return SX_OK;
+}
+
+int sx_profile_collect(int kind, double* total_ms, int64_t* launches) {
+    if (kind < 0 || kind >= SX_PROF_KINDS || !total_ms || !launches) return SX_ERR_ARG;
+    std::lock_guard<std::mutex> lock(sx::g_prof_mu);
+    double tot = 0.0;
+    int64_t n = 0;
+    for (auto& e : sx::g_prof_entries) {
+        if (e.kind != kind) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(e.stop) != hipSuccess || hipEventElapsedTime(&ms, e.start, e.stop) != hipSuccess) {
+            (void)hipGetLastError();
+            return SX_ERR_LAUNCH;
+        }
+        tot += ms;
+        ++n;
+    }
+    *total_ms = tot;
+    *launches = n;
+    return SX_OK;
+}
+
+int sx_profile_disable(void) {
+    std::lock_guard<std::mutex> lock(sx::g_prof_mu);
+    sx::g_prof_on = false;
+    for (auto& e : sx::g_prof_entries) {
+        sx::g_prof_pool.push_back(e.start);
+        sx::g_prof_pool.push_back(e.stop);
+    }
+    sx::g_prof_entries.clear();
+    return SX_OK;
+}
 
 int sx_gp_pack_sizes(int n_s, int n_u, int n_train, int64_t* a_doubles, int64_t* tab_ints) {
     if (n_s <= 0 || n_s > SX_MAX_NS || n_u <= 0 || n_u > SX_MAX_NU || n_train <= 0) return SX_ERR_ARG;
@@ -736,6 +863,7 @@ int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, 
                     actions, (long long)act_stride, elite_idx, elite_rows, mean,     std,
                     best,   best_ok};
     if (P > sx::kRankThreads * sx::kRankSlots) return SX_ERR_UNSUPPORTED;
+    sx::ProfScope prof(SX_PROF_RANK, (hipStream_t)stream);
     const int slots = (P + sx::kRankThreads - 1) / sx::kRankThreads;
     if (slots <= 4)
         hipLaunchKernelGGL(sx::cem_rank_kernel<4>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);

@@ -33,12 +33,17 @@ struct CostConst {
     int con_mode;
 };
 
-// _fix_zeros_nans, per element (gp_reachability_pytorch.py:234-243).  The reference decides on the whole batch:
-// with an exact zero ANYWHERE it also lifts negatives to 1e-5; without one, a negative goes on to sqrt -> NaN -> abort.
-// Here a negative always takes the second route (DESIGN.md "Deviations").
-__device__ __forceinline__ double fix_zero_nan(double x, int& status) {
+// _fix_zeros_nans (gp_reachability_pytorch.py:234-243).  The reference decides on the whole batch: a NaN anywhere fails;
+// an exact zero ANYWHERE lifts every x <= 0 to 1e-5; without one, a negative goes on to sqrt -> NaN -> fails at the next
+// check.  `clamp_nonpos` carries the batch's "an exact zero is present" flag:
+//   * sx_onestep_reach computes it over the batch in a pre-pass (batch_zero_flag_kernel) -- the reference's rule exactly;
+//   * the fused rollout cannot see the other workgroups' particles of the same step and passes false: exact zeros are
+//     lifted, a negative always takes the sqrt -> NaN route.  The two rules differ only when a solve reports BOTH
+//     SX_STATUS_NAN and SX_STATUS_ZERO_FIX; FusedCemMpc then repeats the solve through the step-by-step path
+//     (sx_gp_predict + sx_onestep_reach), which decides as the reference does (DESIGN.md "Deviations").
+__device__ __forceinline__ double fix_zero_nan(double x, int& status, bool clamp_nonpos = false) {
     if (x != x) status |= SX_STATUS_NAN;
-    if (x == 0.0) {
+    if (x == 0.0 || (clamp_nonpos && x <= 0.0)) {
         status |= SX_STATUS_ZERO_FIX;
         x = 1e-5;
     }
@@ -129,10 +134,10 @@ __device__ __forceinline__ double remainder_r2(const ReachConst<NS, NU>& rc, con
 template <int NS, int NU>
 __device__ __forceinline__ void reach_point(const ReachConst<NS, NU>& rc, const double (&p)[NS], const double (&u)[NU],
                                             const double (&mean)[NS], double (&var)[NS], double (&p1)[NS],
-                                            double (&Q1)[NS][NS], int& status) {
+                                            double (&Q1)[NS][NS], int& status, bool batch_zero = false) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        var[i] = fix_zero_nan(var[i], status);
+        var[i] = fix_zero_nan(var[i], status, batch_zero);
         double rk = rc.beta * sqrt(var[i]);
         rk = fix_zero_nan(rk, status);
         if (!(rk > 0.0)) status |= SX_STATUS_UB_NONPOS;
@@ -154,7 +159,7 @@ __device__ __forceinline__ void reach_ellipsoid(const ReachConst<NS, NU>& rc, co
                                                 const double (&Q)[NS][NS], const double (&u)[NU],
                                                 const double (&mean)[NS], double (&var)[NS],
                                                 const double (&jac)[NS][NS + NU], double (&p1)[NS],
-                                                double (&Q1)[NS][NS], int& status) {
+                                                double (&Q1)[NS][NS], int& status, bool batch_zero = false) {
     // H = a + J_x + (J_u + b) k_fb                                             (:131)
     double Hm[NS][NS];
 #pragma unroll
@@ -197,7 +202,7 @@ __device__ __forceinline__ void reach_ellipsoid(const ReachConst<NS, NU>& rc, co
     double trSig = 0.0, trMu = 0.0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        var[i] = fix_zero_nan(var[i], status);
+        var[i] = fix_zero_nan(var[i], status, batch_zero);
         double bs = rc.beta * (sqrt(var[i]) + rc.l_sigma[i] * r1);
         bs = fix_zero_nan(bs, status);
         const double um = rc.l_mu[i] * r2;

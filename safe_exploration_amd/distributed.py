@@ -32,33 +32,38 @@ def rank_seed(seed: int, rank: int) -> int:
     return int(seed) + 1000 * int(rank)
 
 
-def exchange_elite_rows(rows: Tensor, group=None) -> Tensor:
-    """rows [E x k x W] (this rank's local elites, best first) -> [E x G*k x W], rank-major, identical on every rank.
+class EliteExchange:
+    """The per-iteration exchange of one sharded solve: what `FusedCemMpc.solve` runs between its local
+    and its global ranking launch, and what tests/test_distributed_gloo.py drives on the CPU.
 
-    One all-reduce(sum) over zero-padded slots.  Adding zeros is exact in IEEE arithmetic for finite values and keeps
-    +-inf; a NaN cost stays NaN.  (-0.0 + 0.0 = +0.0 does not change any ordering or refit.)
+    One allocation holds the zero-initialised buffers of ALL iterations (one memset per solve).  Iteration `it` owns
+    `[E x G x k x (2 + L)]` candidate slots -- a row is `[con, obj, actions...]` -- plus G trailing cells in which the
+    per-rank status words ride along with the LAST exchange, so a solve has no collective besides its `iterations`
+    all-reduces.  Every rank fills only its own slot; the all-reduce(sum) over the zero padding is all-gather-shaped and
+    exact (x + 0 = x for finite x and +-inf, NaN stays NaN; -0.0 + 0.0 = +0.0 changes neither the order nor the refit).
     """
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    E, k, W = rows.shape
-    buf = torch.zeros((E, world, k, W), dtype=rows.dtype, device=rows.device)
-    buf[:, rank] = rows
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    return buf.view(E, world * k, W)
 
+    def __init__(self, iterations: int, episodes: int, k: int, row_len: int, group, device, dtype=torch.float64):
+        self.group = group
+        self.world, self.rank = world_and_rank(group)
+        self.E, self.k, self.L = episodes, k, row_len
+        self.n_slots = episodes * self.world * k * (2 + row_len)
+        self.buf = torch.zeros((iterations, self.n_slots + self.world), dtype=dtype, device=device)
 
-def all_reduce_slots(buf: Tensor, group=None) -> Tensor:
-    """buf [E x G x k x W], zero everywhere but in this rank's slot [:, rank] -> the same buffer after ONE
-    all-reduce(sum), viewed [E x G*k x W] (what exchange_elite_rows returns, without its allocation and copy)."""
-    E, world, k, W = buf.shape
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    return buf.view(E, world * k, W)
+    def slots(self, it: int) -> Tensor:
+        """[E x G x k x (2 + L)] view of iteration `it`."""
+        return self.buf[it, :self.n_slots].view(self.E, self.world, self.k, 2 + self.L)
 
+    def local_slot(self, it: int) -> Tensor:
+        """This rank's [E x k x (2 + L)] slot (contiguous when E == 1: the rank kernel then writes straight into it)."""
+        return self.slots(it)[:, self.rank]
 
-def all_reduce_sum_(buf: Tensor, group=None) -> None:
-    """In-place all-reduce(sum) of a buffer in which every rank has filled only its own cells (zeros elsewhere):
-    all-gather-shaped, and adding zeros is exact."""
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-
-
-def all_reduce_max_(t: Tensor, group=None) -> None:
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    def exchange(self, it: int, status: Optional[Tensor] = None):
+        """The ONE collective of iteration `it`.  Returns (candidates [E x G*k x (2 + L)], status words int32 [G] or
+        None): with `status` (this rank's int32 [1] word, passed on the last iteration) every rank learns the words of
+        all ranks, so that all ranks raise, or not, together."""
+        if status is not None:
+            self.buf[it, self.n_slots + self.rank] = status[0]
+        dist.all_reduce(self.buf[it], op=dist.ReduceOp.SUM, group=self.group)
+        words = self.buf[it, self.n_slots:].to(torch.int32) if status is not None else None
+        return self.slots(it).view(self.E, self.world * self.k, 2 + self.L), words

@@ -59,9 +59,33 @@ def _host(x) -> Optional[np.ndarray]:
     return None if x is None else x.detach().cpu().numpy()
 
 
-def raise_for_status(status: int, where: str) -> None:
-    """Maps the device status word onto the reference's failure modes."""
+FAILURE_DUMP_PATH = 'negative_variance_state.pt'   # the reference's file name (gp_reachability_pytorch.py:266)
+
+
+def save_failure_state(ssm, state: Tensor, action: Tensor, path: Optional[str] = None) -> Optional[str]:
+    """What the reference's ``_save_model`` writes before it raises on a numerical failure
+    (gp_reachability_pytorch.py:256-266): the GP's hyper-parameter state, the offending states and actions and the
+    training data, as one ``torch.save`` file in the working directory.  Returns the path (None if the model has no
+    state to save or the file cannot be written: the dump must never mask the error it accompanies)."""
+    path = path or FAILURE_DUMP_PATH
+    try:
+        sd = ssm.state_dict() if hasattr(ssm, 'state_dict') else {}
+        cpu = lambda t: None if t is None else t.detach().cpu()
+        torch.save({'gp_model': sd.get('gp_model', {}), 'gp_likelihood': sd.get('gp_likelihood', {}),
+                    'state': cpu(state), 'action': cpu(action), 'x_train': cpu(getattr(ssm, 'x_train', None)),
+                    'y_train': cpu(getattr(ssm, 'y_train', None))}, path)
+        return path
+    except Exception as exc:   # noqa: BLE001 -- diagnostics only
+        print(f'WARNING: could not write {path}: {exc}')
+        return None
+
+
+def raise_for_status(status: int, where: str, dump=None) -> None:
+    """Maps the device status word onto the reference's failure modes.  `dump`, if given, is called before the
+    ValueError of a numerical failure is raised (the reference saves the model state first, :78-80, :256-266)."""
     if status & _lib.SX_STATUS_NAN:
+        if dump is not None:
+            dump()
         raise ValueError(f'nan in {where} (sigm_0 / rkhs_bounds / b_sigma_eps): numerical failure in the GP variance')
     if status & _lib.SX_STATUS_UB_NONPOS:
         raise AssertionError('All elements of u_b must be >0')
@@ -112,7 +136,7 @@ def onestep_reachability(p_center: Tensor, ssm: CemSSM, k_ff: Tensor, l_mu: Tens
                                            _lib.ptr(mean.detach().contiguous()), _lib.ptr(var.detach().contiguous()),
                                            _lib.ptr(jac), _lib.ptr(p1), _lib.ptr(q1), _lib.ptr(sigma),
                                            _lib.ptr(status), _lib.stream_ptr(dev)), 'sx_onestep_reach')
-    raise_for_status(int(status.item()), 'onestep_reachability')
+    raise_for_status(int(status.item()), 'onestep_reachability', dump=lambda: save_failure_state(ssm, p, u))
     return p1, q1, sigma
 
 

@@ -86,6 +86,20 @@ class GpCemSSM(CemSSM):
         if self._x_train is not None:
             self._update_model(self._x_train, self._y_train)
 
+    def state_dict(self) -> Dict[str, Dict[str, Tensor]]:
+        """The hyper-parameter state, split the way the reference's failure dump stores it (model / likelihood:
+        gp_reachability_pytorch.py:256-266); `load_state_dict` takes it back."""
+        return {'gp_model': {'raw_lengthscale': self._raw_lengthscale.clone(), 'raw_outputscale': self._raw_outputscale.clone()},
+                'gp_likelihood': {'raw_noise': self._raw_noise.clone(), 'noise_floor': torch.tensor(self._noise_floor)}}
+
+    def load_state_dict(self, state: Dict[str, Dict[str, Tensor]]) -> None:
+        self._raw_lengthscale = state['gp_model']['raw_lengthscale'].clone()
+        self._raw_outputscale = state['gp_model']['raw_outputscale'].clone()
+        self._raw_noise = state['gp_likelihood']['raw_noise'].clone()
+        self._noise_floor = float(state['gp_likelihood']['noise_floor'])
+        if self._x_train is not None:
+            self._update_model(self._x_train, self._y_train)
+
     # ---- model (re)build: the warm path ------------------------------------------------------------------------
     def _fit(self, x: Tensor, y: Tensor):
         """sx_gp_fit for the current hyper-parameters.  Returns (model struct, linv, alpha, logdet); raises if the

@@ -1,5 +1,7 @@
-"""CPU, 2 processes, gloo: the N > 1 data path of the solver -- shard the particles, keep local elites, ONE all-reduce over
-zero-padded slots, every rank ranks the same candidates.  The kernels' part (local ranking) is played by the oracle."""
+"""CPU, 2 processes, gloo: the N > 1 data path of the solver.  `distributed.EliteExchange` is the code
+`FusedCemMpc.solve` runs between its local and its global ranking launch (particle sharding, zero-padded slots, ONE
+all-reduce per iteration, status words riding along with the last one); here the two launches around it are played by
+the oracle's ranking, so the whole exchange runs without a GPU."""
 import os
 import socket
 
@@ -21,43 +23,78 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, port, P, k, L, out):
+def _worker(rank, port, P, k, L, E, iters, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
-        rng = np.random.default_rng(7)                 # the same global population on both ranks
-        con = rng.choice([0., 0., 3., 10.], size=P)
-        obj = rng.normal(size=P)
-        act = rng.normal(size=(P, L))
-        count, off = distributed.shard_particles(P, WORLD, rank)
-        idx = ocem.rank(con[off:off + count], obj[off:off + count], k) + off       # local elites (the kernel's job)
-        rows = np.concatenate((con[idx, None], obj[idx, None], act[idx]), axis=1)   # [k x (2 + L)]
-        cand = distributed.exchange_elite_rows(torch.tensor(rows[None]), dist.group.WORLD)[0].numpy()
-        assert cand.shape == (WORLD * k, 2 + L)
-        np.testing.assert_array_equal(cand[rank * k:(rank + 1) * k], rows)         # own slot untouched
-        # the form the solver uses: the rows are written straight into this rank's slot of a zeroed buffer
-        buf = torch.zeros((1, WORLD, k, 2 + L), dtype=torch.float64)
-        buf[0, rank] = torch.tensor(rows)
-        cand2 = distributed.all_reduce_slots(buf, dist.group.WORLD)
-        assert cand2.data_ptr() == buf.data_ptr()                                   # in place, no copy
-        np.testing.assert_array_equal(cand2[0].numpy(), cand)
-        # global selection from the candidates == selection from the whole population
-        sel = ocem.rank(cand[:, 0], cand[:, 1], k)
-        want = ocem.rank(con, obj, k)
-        np.testing.assert_array_equal(cand[sel][:, 2:], act[want])
-        mean, std = ocem.refit(cand[sel][:, 2:].reshape(k, L, 1))
-        st = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
-        distributed.all_reduce_max_(st, dist.group.WORLD)
-        assert int(st) == 1
-        out[rank] = np.concatenate((mean.ravel(), std.ravel())).tobytes()           # must be bit-identical on all ranks
+        xch = distributed.EliteExchange(iters, E, k, L, dist.group.WORLD, 'cpu')
+        assert (xch.world, xch.rank) == (WORLD, rank) and tuple(xch.slots(0).shape) == (E, WORLD, k, 2 + L)
+        count, off = distributed.shard_particles(P, WORLD, rank)   # uneven when P is odd: the first rank takes one more
+        digest = b''
+        for it in range(iters):
+            rng = np.random.default_rng(7 + it)                    # the same global population on both ranks
+            con = rng.choice([0., 0., 3., 10.], size=(E, P))
+            obj = rng.normal(size=(E, P))
+            act = rng.normal(size=(E, P, L))
+            for e in range(E):                                     # local elites (on the GPU: cem_rank_kernel's job)
+                idx = ocem.rank(con[e, off:off + count], obj[e, off:off + count], k) + off
+                rows = np.concatenate((con[e, idx, None], obj[e, idx, None], act[e, idx]), axis=1)   # [k x (2 + L)]
+                xch.local_slot(it)[e] = torch.tensor(rows)
+            last = it == iters - 1
+            status = torch.tensor([4 if rank == 1 else 0], dtype=torch.int32)
+            before = xch.local_slot(it).clone()
+            cand, words = xch.exchange(it, status if last else None)
+            assert cand.data_ptr() == xch.buf[it].data_ptr()                       # in place, no copy
+            assert tuple(cand.shape) == (E, WORLD * k, 2 + L)
+            np.testing.assert_array_equal(xch.local_slot(it).numpy(), before.numpy())   # own slot untouched by the sum
+            if last:
+                assert words.dtype == torch.int32 and words.tolist() == [0, 4]     # every rank sees every rank's word
+            else:
+                assert words is None
+            for e in range(E):
+                c = cand[e].numpy()
+                # global selection from the G k candidates == selection from the whole population
+                sel = ocem.rank(c[:, 0], c[:, 1], k)
+                want = ocem.rank(con[e], obj[e], k)
+                np.testing.assert_array_equal(c[sel][:, 2:], act[e, want])
+                mean, std = ocem.refit(c[sel][:, 2:].reshape(k, L, 1))
+                digest += np.concatenate((mean.ravel(), std.ravel())).tobytes()
+        out[rank] = digest                                                          # must be bit-identical on all ranks
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_elite_exchange_world2():
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize('P,k,L,E,iters', [(1000, 16, 5, 1, 2), (193, 24, 3, 2, 3)])
+def test_elite_exchange_world2(P, k, L, E, iters):
     port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(port, 1001, 16, 5, out), nprocs=WORLD, join=True)
+        mp.spawn(_worker, args=(port, P, k, L, E, iters, out), nprocs=WORLD, join=True)
         assert len(out) == WORLD and out[0] == out[1]
+
+
+def test_constructor_refuses_what_the_exchange_cannot_serve():
+    """More elites than the smallest per-GPU share would make a rank hand in fewer than k rows: refused up
+    front, with the kernel's limits (no GPU needed: the checks run before anything touches the device)."""
+    from safe_exploration_amd import cem_mpc
+
+    class _Ssm:
+        num_states, num_actions = 2, 1
+
+    class _Group:
+        pass
+
+    orig = distributed.world_and_rank
+    distributed.world_and_rank = lambda g: (2, 0) if g is not None else (1, 0)
+    try:
+        with pytest.raises(ValueError, match='smallest per-GPU share'):
+            cem_mpc.FusedCemMpc(_Ssm(), None, 5, 5, 3, 2, device='cpu', process_group=_Group())
+        with pytest.raises(ValueError, match='limit'):
+            cem_mpc.FusedCemMpc(_Ssm(), None, 5, 40000, 10, 2, device='cpu')
+        with pytest.raises(ValueError, match='limit'):
+            cem_mpc.FusedCemMpc(_Ssm(), None, 5, 16384, 4096, 2, device='cpu')
+        with pytest.raises(ValueError, match='warm_start'):
+            cem_mpc.FusedCemMpc(_Ssm(), None, 5, 64, 8, 2, device='cpu', warm_start='lqr')
+    finally:
+        distributed.world_and_rank = orig

@@ -55,7 +55,18 @@ def _worker(rank, port, out):
             assert (ref_e is not None) == bool(ok2[e])
             if ref_e is not None:
                 np.testing.assert_allclose(best2[e].cpu().numpy(), ref_e, rtol=0, atol=1e-9)
-        out[rank] = best[0].cpu().numpy().tobytes() + best2.cpu().numpy().tobytes()
+        # uneven shards (193 = 97 + 96): every rank still hands in k rows, the global top-k misses nothing
+        from safe_exploration_amd import distributed
+        P3 = 193
+        noise3 = rng.normal(size=(iters, P3, H, 1))
+        mpc3 = FusedCemMpc(ssm, env, H, P3, k, iters, device=dev, init_std=0.2, process_group=dist.group.WORLD)
+        cnt, off = distributed.shard_particles(P3, WORLD, rank)
+        best3, ok3, _, status3 = mpc3.solve(t(x0[None]), noise=t(noise3[:, None, off:off + cnt]))
+        ref3, _ = ocem.cem_solve(problems.oracle_problem(spec, ocem), gp, x0, noise3, k, init_std=np.full((H, 1), 0.2))
+        assert not bool(status3.any()) and (ref3 is not None) == bool(ok3[0])
+        if ref3 is not None:
+            np.testing.assert_allclose(best3[0].cpu().numpy(), ref3, rtol=0, atol=1e-9)
+        out[rank] = best[0].cpu().numpy().tobytes() + best2.cpu().numpy().tobytes() + best3.cpu().numpy().tobytes()
     finally:
         dist.destroy_process_group()
 

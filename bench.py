@@ -114,6 +114,39 @@ def cpu_baseline(w, budget_s=12.0):
                       f'OpenMP over particles, float64), {dt:.1f} s'}
 
 
+def roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, cfg):
+    """The `roofline` object of the JSON line, for the kernel that took the largest share of the timed region."""
+    dominant = max(kernels, key=lambda k: kernels[k][0])
+    avg_s = kernels[dominant][0] / kernels[dominant][1] * 1e-3
+    if dominant == 'trmm_reduce_kernel':
+        units = E * P                                # particle-steps one launch processes (one step of all particles)
+        n_mfma = mfma_per_launch_trmm(spec.n_s, n_train, d_in, E * P)
+    else:
+        units = E * P * H                            # one launch = the whole rollout
+        n_mfma = mfma_per_launch_fused(spec.n_s, n_train, d_in, E * ((P + 15) // 16), H)
+    executed = n_mfma * MFMA_FLOPS / avg_s / 1e12
+    algorithmic = flops_unit * units / avg_s / 1e12
+    frac = executed / F64_MATRIX_PEAK_TFLOPS
+    assert frac <= 1.0, f'roofline fraction {frac} > 1: the flop count or the timer is wrong'
+    pmc = pmc_summary(cfg)
+    traffic = None
+    if pmc and pmc.get('workload') == f'cfg{cfg} N_train={n_train} H={H} P={P} E={E}':
+        traffic = pmc.get('hbm_traffic_bytes_per_launch', {}).get(dominant)
+    return {'bound': 'mfma', 'achieved': executed, 'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': frac, 'kernel': dominant, 'avg_launch_us': avg_s * 1e6, 'launches_timed': kernels[dominant][1],
+            'flops': 'EXECUTED: v_mfma_f64_16x16x4 instructions per launch (analytic count of the triangular form, equal '
+                     'to SQ_INSTS_MFMA) x 2048',
+            'mfma_instructions_per_launch': n_mfma,
+            'algorithmic_tflops': algorithmic,
+            'algorithmic_flops_per_launch': flops_unit * units,
+            'algorithmic_note': 'SURVEY 8d counts 2 N^2 per output for K* Kinv; the kernel evaluates ||L^-1 k*||^2 (N^2), so '
+                                'algorithmic_tflops may exceed the peak',
+            'traffic': traffic,
+            'traffic_unit': 'B/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950; '
+                            'profiles/r02_pmc_cfg*.json)',
+            'hbm_gb_per_s': (traffic / avg_s / 1e9) if traffic else None}
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -150,10 +183,16 @@ def main():
     ap.add_argument('--iters', type=int, default=0, help='CEM iterations per solve (reference default 8)')
     ap.add_argument('--elites', type=int, default=0, help='0 = 10 %% of the per-GPU particle count')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true', help='leave the per-launch HIP events off (no roofline object)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # stdout carries ONE JSON line and nothing else: whatever the libraries below print to fd 1 (gloo's connection
+    # banner, for one) goes to stderr; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -214,7 +253,11 @@ def main():
     for _ in range(warmup):
         mpc.solve(x0)
     lib = _lib.lib()
-    _lib.check(lib.sx_profile_enable(max(4096, steps * iters * (3 * H + 4))), 'sx_profile_enable')
+    if not args.no_kernel_timer:
+        # HIP events on every 4th launch of each kernel (every launch of the large-N path, whose kernels run for
+        # milliseconds): timing every 130 us launch costs the solve ~7 % (measured), every 4th < 2 %
+        _lib.check(lib.sx_profile_stride(1 if w.cfg == 4 else 4), 'sx_profile_stride')
+        _lib.check(lib.sx_profile_enable(max(4096, steps * iters * (3 * H + 4))), 'sx_profile_enable')
     if world > 1 and w.sharded:
         mpc.exchange_events = []
     barrier()
@@ -228,8 +271,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
     status_word = fold_status(status.cpu())
-    kernels = _lib.profile_collect()                 # {kernel: (total ms, launches)}, HIP events on the launch stream
-    _lib.check(lib.sx_profile_disable(), 'sx_profile_disable')
+    kernels = {}
+    if not args.no_kernel_timer:
+        kernels = _lib.profile_collect()             # {kernel: (total ms, launches)}, HIP events on the launch stream
+        _lib.check(lib.sx_profile_disable(), 'sx_profile_disable')
     exchange_us = None
     if mpc.exchange_events:
         xs = [a.elapsed_time(b) for a, b in mpc.exchange_events]
@@ -251,22 +296,9 @@ def main():
             flops_unit = algorithmic_flops_per_particle_step(spec.n_s, n_train, d_in)
             per_kernel = {k: {'avg_launch_us': ms / n * 1e3, 'launches': n, 'share_of_step': ms / (elapsed * 1e3)}
                           for k, (ms, n) in kernels.items()}
-            dominant = max(kernels, key=lambda k: kernels[k][0])
-            avg_s = kernels[dominant][0] / kernels[dominant][1] * 1e-3
-            if dominant == 'trmm_reduce_kernel':
-                units = E * P                                # particle-steps one launch processes (one step of all particles)
-                n_mfma = mfma_per_launch_trmm(spec.n_s, n_train, d_in, E * P)
-            else:
-                units = E * P * H                            # one launch = the whole rollout
-                n_mfma = mfma_per_launch_fused(spec.n_s, n_train, d_in, E * ((P + 15) // 16), H)
-            executed = n_mfma * MFMA_FLOPS / avg_s / 1e12
-            algorithmic = flops_unit * units / avg_s / 1e12
-            frac = executed / F64_MATRIX_PEAK_TFLOPS
-            assert frac <= 1.0, f'roofline fraction {frac} > 1: the flop count or the timer is wrong'
-            pmc = pmc_summary(w.cfg)
-            traffic = None
-            if pmc and pmc.get('workload') == f'cfg{w.cfg} N_train={n_train} H={H} P={P} E={E}':
-                traffic = pmc.get('hbm_traffic_bytes_per_launch', {}).get(dominant)
+            roofline = None
+            if kernels:
+                roofline = roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, w.cfg)
             out = {
                 'metric': 'cem_particle_step_evals_per_s', 'value': particle_steps / elapsed, 'unit': 'particle-steps/s',
                 'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
@@ -284,27 +316,14 @@ def main():
                 'particle_rollouts_per_s': particle_steps / H / elapsed,
                 'device_status': status_word, 'solution_found': bool(ok[0].item()),
                 'exchange_us': exchange_us,
-                'roofline': {'bound': 'mfma', 'achieved': executed, 'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': frac, 'kernel': dominant, 'avg_launch_us': avg_s * 1e6,
-                             'launches_timed': kernels[dominant][1],
-                             'flops': 'EXECUTED: v_mfma_f64_16x16x4 instructions per launch (analytic count of the '
-                                      'triangular form, equal to SQ_INSTS_MFMA) x 2048',
-                             'mfma_instructions_per_launch': n_mfma,
-                             'algorithmic_tflops': algorithmic,
-                             'algorithmic_flops_per_launch': flops_unit * units,
-                             'algorithmic_note': 'SURVEY 8d counts 2 N^2 per output for K* Kinv; the kernel evaluates '
-                                                 '||L^-1 k*||^2 (N^2), so algorithmic_tflops may exceed the peak',
-                             'traffic': traffic,
-                             'traffic_unit': 'B/launch (rocprofv3 FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md '
-                                             'prescribes; profiles/r02_pmc_cfg*.json)',
-                             'hbm_gb_per_s': (traffic / avg_s / 1e9) if traffic else None},
+                'roofline': roofline,
                 'kernels': per_kernel,
             }
             if world == 1 and not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(w)
                 if w.cfg == 2:
                     out['cpu_baseline']['reference_measured_elsewhere'] = REFERENCE_CPU
-            print(json.dumps(out), flush=True)
+            os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1:
         dist.barrier(group)
         dist.destroy_process_group()

@@ -102,6 +102,8 @@ const char* sx_version(void);
 #define SX_PROF_STEP_BIG 4       /* step_big_kernel    (large-N path) */
 #define SX_PROF_KINDS 5
 int sx_profile_enable(int max_launches);
+int sx_profile_stride(int every);   /* time every n-th launch of a kernel class only (default 1): an event pair costs the
+                                       launch path a few microseconds, which a 130 us kernel notices */
 int sx_profile_collect(int kind, double* total_ms, int64_t* launches);
 int sx_profile_disable(void);
 

@@ -1,5 +1,6 @@
 // libsxamd: launchers + C ABI (include/sx_amd.h) over the kernels in sx_*.hpp.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -284,36 +285,46 @@ struct ProfEntry {
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static size_t g_prof_cap = 0;
+static int g_prof_stride = 1;               // every n-th launch of a kernel class is timed
+static long g_prof_seen[SX_PROF_KINDS] = {0};
 static std::vector<ProfEntry> g_prof_entries;
 static std::vector<hipEvent_t> g_prof_pool;
 
-struct ProfScope {
-    hipStream_t stream;
-    hipEvent_t stop = nullptr;
-    ProfScope(int kind, hipStream_t s) : stream(s) {
-        if (!g_prof_on) return;   // (read without the lock: enabling mid-launch only loses that launch)
-        std::lock_guard<std::mutex> lock(g_prof_mu);
-        if (!g_prof_on || g_prof_entries.size() >= g_prof_cap) return;
-        auto take = [&]() {
-            hipEvent_t e = nullptr;
-            if (!g_prof_pool.empty()) {
-                e = g_prof_pool.back();
-                g_prof_pool.pop_back();
-            } else if (hipEventCreate(&e) != hipSuccess) {
-                e = nullptr;
-            }
-            return e;
-        };
-        hipEvent_t a = take(), b = take();
-        if (!a || !b) return;
-        (void)hipEventRecord(a, stream);
-        g_prof_entries.push_back(ProfEntry{kind, a, b});
-        stop = b;
-    }
-    ~ProfScope() {
-        if (stop) (void)hipEventRecord(stop, stream);
-    }
-};
+// Takes a (start, stop) event pair for one launch of kernel class `kind`, or returns false (timer off / cap reached).
+static bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop) {
+    if (!g_prof_on) return false;   // (read without the lock: enabling mid-launch only loses that launch)
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (!g_prof_on || g_prof_entries.size() >= g_prof_cap) return false;
+    if ((g_prof_seen[kind]++ % g_prof_stride) != 0) return false;
+    auto take = [&]() {
+        hipEvent_t e = nullptr;
+        if (!g_prof_pool.empty()) {
+            e = g_prof_pool.back();
+            g_prof_pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
+        }
+        return e;
+    };
+    hipEvent_t a = take(), b = take();
+    if (!a || !b) return false;
+    g_prof_entries.push_back(ProfEntry{kind, a, b});
+    *start = a;
+    *stop = b;
+    return true;
+}
+
+// Every kernel of the path is launched through here.  With the timer on, the events ride on the dispatch packet itself
+// (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps, no extra barrier packets on the stream); otherwise
+// this is a plain launch.
+template <typename F, typename... Args>
+static void launch(int kind, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+    hipEvent_t start = nullptr, stop = nullptr;
+    if (prof_take(kind, &start, &stop))
+        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, stream, start, stop, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
 
 static int check_launch() {
     const hipError_t err = hipGetLastError();
@@ -486,21 +497,14 @@ static int launch_rollout_big(const sx_gp_model* m, const sx_env* env, const Rol
     hipLaunchKernelGGL((init_big_kernel<NS, NU>), dim3((unsigned)((p128 + 255) / 256)), dim3(256), 0, stream, bi, ws, total,
                        p128);
     for (int t = 0; t < rp.H; ++t) {
-        {
-            ProfScope prof(SX_PROF_KSTAR_BIG, stream);
-            hipLaunchKernelGGL((kstar_big_kernel<NS, D>), dim3((unsigned)(p128 / 16), (unsigned)((m->n_pad + 255) / 256)),
-                               dim3(256), 0, stream, gc, ws);
-        }
-        {
-            ProfScope prof(SX_PROF_TRMM_BIG, stream);
-            hipLaunchKernelGGL((trmm_reduce_kernel<NS, D>), dim3((unsigned)(p128 / kBigTile), (unsigned)row_tiles, NS),
-                               dim3(kBigThreads), 0, stream, gc, ws, p128);
-        }
+        launch(SX_PROF_KSTAR_BIG, kstar_big_kernel<NS, D>, dim3((unsigned)(p128 / 16), (unsigned)((m->n_pad + 255) / 256)),
+               dim3(256), 0, stream, gc, ws);
+        launch(SX_PROF_TRMM_BIG, trmm_reduce_kernel<NS, D>, dim3((unsigned)(p128 / kBigTile), (unsigned)row_tiles, NS),
+               dim3(kBigThreads), 0, stream, gc, ws, p128);
         BigStep bs{rp.actions, rp.traj, rp.sigma, rp.obj_cost, rp.con_cost, rp.status, rp.H, t, row_tiles * 2,
                    (t > 0 || rp.q0 != nullptr) ? 1 : 0};
-        ProfScope prof(SX_PROF_STEP_BIG, stream);
-        hipLaunchKernelGGL((step_big_kernel<NS, NU>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0, stream, gc, rc, cc, bs,
-                           ws, total, p128);
+        launch(SX_PROF_STEP_BIG, step_big_kernel<NS, NU>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, stream, gc, rc, cc,
+               bs, ws, total, p128);
     }
     return check_launch();
 }
@@ -520,15 +524,14 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
     const size_t lds = (gp_tile_lds_doubles(NS, NS + NU, m->n_train, m->n_pad, nw, all_at_once ? NS : 1) +
                         (size_t)SX_TILE * rp.H * NU) * sizeof(double);
     const int tiles = (rp.P + SX_TILE - 1) / SX_TILE;
-    ProfScope prof(SX_PROF_ROLLOUT_FUSED, stream);
     if (all_at_once) {
         if (int r = allow_lds(cem_rollout_kernel<NS, NU, false>, lds)) return r;
-        hipLaunchKernelGGL((cem_rollout_kernel<NS, NU, false>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc,
-                           gc.stage_tab, rc, cc, rp);
+        launch(SX_PROF_ROLLOUT_FUSED, cem_rollout_kernel<NS, NU, false>, dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream,
+               gc, gc.stage_tab, rc, cc, rp);
     } else {
         if (int r = allow_lds(cem_rollout_kernel<NS, NU, true>, lds)) return r;
-        hipLaunchKernelGGL((cem_rollout_kernel<NS, NU, true>), dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream, gc,
-                           gc.stage_tab, rc, cc, rp);
+        launch(SX_PROF_ROLLOUT_FUSED, cem_rollout_kernel<NS, NU, true>, dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream,
+               gc, gc.stage_tab, rc, cc, rp);
     }
     return check_launch();
 }
@@ -568,7 +571,15 @@ int sx_profile_enable(int max_launches) {
     }
     sx::g_prof_entries.clear();
     sx::g_prof_cap = (size_t)max_launches;
+    for (long& n : sx::g_prof_seen) n = 0;
     sx::g_prof_on = true;
+    return SX_OK;
+}
+
+int sx_profile_stride(int every) {
+    if (every <= 0) return SX_ERR_ARG;
+    std::lock_guard<std::mutex> lock(sx::g_prof_mu);
+    sx::g_prof_stride = every;
     return SX_OK;
 }
 
@@ -863,14 +874,13 @@ int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, 
                     actions, (long long)act_stride, elite_idx, elite_rows, mean,     std,
                     best,   best_ok};
     if (P > sx::kRankThreads * sx::kRankSlots) return SX_ERR_UNSUPPORTED;
-    sx::ProfScope prof(SX_PROF_RANK, (hipStream_t)stream);
     const int slots = (P + sx::kRankThreads - 1) / sx::kRankThreads;
     if (slots <= 4)
-        hipLaunchKernelGGL(sx::cem_rank_kernel<4>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
+        sx::launch(SX_PROF_RANK, sx::cem_rank_kernel<4>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
     else if (slots <= 8)
-        hipLaunchKernelGGL(sx::cem_rank_kernel<8>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
+        sx::launch(SX_PROF_RANK, sx::cem_rank_kernel<8>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
     else
-        hipLaunchKernelGGL(sx::cem_rank_kernel<sx::kRankSlots>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
+        sx::launch(SX_PROF_RANK, sx::cem_rank_kernel<sx::kRankSlots>, dim3(E), dim3(sx::kRankThreads), 0, (hipStream_t)stream, ra);
     return sx::check_launch();
 }
 

@@ -1,16 +1,18 @@
-"""Fold the rocprofv3 --pmc passes of bench.py into profiles/<name>.json (per-launch averages of the two kernels).
+"""Fold the rocprofv3 --pmc passes of bench.py into profiles/r<NN>_pmc_cfg<N>.json (per-launch averages per kernel).
 
-On the GPU box (counters in passes of their own, never together with a runtime trace):
+On the GPU box (counters in passes of their own, never together with a runtime trace; tools/profile_config.sh does all
+of it for one config):
 
     cd /tmp && export TMPDIR=/tmp
-    B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+    B="python3 $GRAFT_REPO_ROOT/bench.py --config N --steps 2 --warmup 1 --no-cpu-baseline"
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- $B
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- $B
     rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU \\
               SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq -- $B
 
-then here:  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq > profiles/rNN_pmc_summary.json
+then:  python tools/pmc_summary.py --workload "cfgN N_train=.. H=.. P=.. E=.." DIR... > profiles/rNN_pmc_cfgN.json
 """
+import argparse
 import csv
 import glob
 import json
@@ -18,43 +20,54 @@ import os
 import sys
 from collections import defaultdict
 
-# (needle: the all-outputs-at-once instantiation of the rollout kernel; its third template argument is BYOUT = false)
-KERNELS = {'cem_rollout_kernel<2,1>': 'cem_rollout_kernel<2, 1, false>', 'cem_rank_kernel<4>': 'cem_rank_kernel<4>'}
+KERNELS = ['cem_rollout_kernel', 'cem_rank_kernel', 'trmm_reduce_kernel', 'kstar_big_kernel', 'step_big_kernel']
 
 
-def main(dirs):
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', required=True, help='the key bench.py matches: "cfgN N_train=.. H=.. P=.. E=.."')
+    ap.add_argument('--command', default='')
+    ap.add_argument('dirs', nargs='+')
+    args = ap.parse_args()
     sums = defaultdict(lambda: defaultdict(float))
     counts = defaultdict(lambda: defaultdict(int))
-    for d in dirs:
+    full_names = {}
+    for d in args.dirs:
         for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             with open(path) as f:
                 for row in csv.DictReader(f):
                     name = row['Kernel_Name']
-                    for key, needle in KERNELS.items():
-                        if needle.replace(' ', '') in name.replace(' ', ''):
+                    for key in KERNELS:
+                        if key in name:
                             sums[key][row['Counter_Name']] += float(row['Counter_Value'])
                             counts[key][row['Counter_Name']] += 1
+                            full_names[key] = name
     per_launch = {k: {c: sums[k][c] / counts[k][c] for c in sorted(sums[k])} for k in sums}
+    launches = {k: max(counts[k].values()) for k in counts}
     out = {
-        'command': 'rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline '
-                   '(three separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*); tools/pmc_summary.py',
-        'workload': 'cfg2 pendulum N_train=200 H=15 P=4096',
+        'command': args.command or 'rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --config N '
+                                   '--steps 2 --warmup 1 --no-cpu-baseline (three separate passes: FETCH_SIZE | WRITE_SIZE | '
+                                   'SQ_*); tools/pmc_summary.py',
+        'workload': args.workload,
+        'kernel_names': full_names,
+        'launches_counted': launches,
         'per_launch_averages': per_launch,
         'notes': [
             'FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide '
-            'coalesced reads on gfx950',
+            'coalesced reads on gfx950; Infinity-Cache hits are counted, not excluded',
             'SQ_VALU_MFMA_BUSY_CYCLES = 64 x SQ_INSTS_MFMA exactly: one v_mfma_f64_16x16x4_f64 occupies the pipe for 64 cycles',
             'mfma_pipe_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)',
         ],
+        'hbm_traffic_bytes_per_launch': {}, 'mfma_pipe_busy_fraction': {},
     }
-    r = per_launch.get('cem_rollout_kernel<2,1>', {})
-    if 'FETCH_SIZE' in r and 'WRITE_SIZE' in r:
-        out['hbm_traffic_bytes_per_launch'] = {'cem_rollout_kernel<2,1>': (2 * r['FETCH_SIZE'] + r['WRITE_SIZE']) * 1024}
-    if 'SQ_VALU_MFMA_BUSY_CYCLES' in r and 'GRBM_GUI_ACTIVE' in r:
-        out['mfma_pipe_busy_fraction'] = r['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * r['GRBM_GUI_ACTIVE'] / 8)
+    for k, r in per_launch.items():
+        if 'FETCH_SIZE' in r and 'WRITE_SIZE' in r:
+            out['hbm_traffic_bytes_per_launch'][k] = (2 * r['FETCH_SIZE'] + r['WRITE_SIZE']) * 1024
+        if r.get('SQ_VALU_MFMA_BUSY_CYCLES') and r.get('GRBM_GUI_ACTIVE'):
+            out['mfma_pipe_busy_fraction'][k] = r['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * r['GRBM_GUI_ACTIVE'] / 8)
     json.dump(out, sys.stdout, indent=1)
     print()
 
 
 if __name__ == '__main__':
-    main(sys.argv[1:])
+    main()

@@ -147,22 +147,94 @@ __global__ __launch_bounds__(256) void kstar_big_kernel(GpConst<NS, D> gc, BigWs
 }
 
 // ---- 2. triangular product + row reduction ---------------------------------------------------------------------------
-// grid (P128 / 128, row tiles, NS); 4 waves: wave w owns row-blocks 4 (w >> 1) .. +3 and particle tiles 4 (w & 1) .. +3
-template <int NS, int D>
-__global__ __launch_bounds__(kBigThreads) void trmm_reduce_kernel(GpConst<NS, D> gc, BigWs ws, int64_t p128) {
-    __shared__ __attribute__((aligned(16))) v2d sA[kBigRb][2][64];
-    __shared__ __attribute__((aligned(16))) v2d sB[kBigRb][2][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// T = W_d . Kstar_d^T, 128 rows x 128 particles per workgroup; 4 waves, wave w owns row-blocks 4 (w >> 1) .. +3 and particle
+// tiles 4 (w & 1) .. +3 (4 x 4 accumulators of 16 x 16).
+//
+// The f64 MFMA runs on the SIMD's f64 FMA lanes: every VALU instruction takes cycles from it (tools/overlap_probe.hip).
+// Round 1's kernel spent 1.8 VALU instructions per MFMA on 64-bit address arithmetic and bounds selects, staged both
+// operands through registers and needed two barriers per 64 MFMAs (profiles/r02_pmc_cfg4.json: matrix pipe 75 % busy).
+// Here a K-chunk (2 fragment pairs = 16 k: 16 KB of W, 16 KB of Kstar) goes global -> LDS by 32 `buffer_load ... lds`
+// pieces of 1 KB -- one fragment each, the fragment order of both operands IS the lane-linear image the DMA writes --,
+// 8 per wave, addressed by SGPR offsets only (a constant per piece + 1 KB per pair); two LDS buffers, ONE barrier per chunk,
+// the DMA of chunk c + 1 in flight under the 64 MFMAs per wave of chunk c.  W fragments beyond a row-block's diagonal are
+// whatever follows in memory: the MFMAs that would read them are skipped (wave-uniformly); row-blocks beyond the matrix
+// read zeros (buffer bounds).
+//
+// Grid: 1-D, LONGEST TILE FIRST.  W is triangular: row tile rt has (rt + 1) / row_tiles of the last tile's K extent, a
+// 16-fold spread at N = 2000.  Dealt out in ascending order the long tiles start last and the launch ends in a tail of a
+// few busy CUs (7.2 ms at config 4); in descending order the short tiles fill the gaps the long ones leave (3.9 ms).  With
+// every workgroup reading ONE W tile and ONE Kstar tile (no fabric traffic at all) the times are the same: the kernel is
+// bound by MFMA issue and by how evenly the tiles pack, not by HBM (8 - 11 GB per launch at ~2 TB/s).
+// PPC = fragment pairs per K-chunk (1 or 2: 8 or 16 k), NBUF = LDS buffers (NBUF - 1 chunks of DMA in flight).
+template <int PPC, int NBUF>
+constexpr int big_lds_bytes() { return NBUF * 2 * kBigRb * PPC * 64 * 16; }   // [buffer][W | Kstar][block][pair][lane] x 16 B
+
+template <int NS, int D, int PPC, int NBUF>
+__global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <= 4 ? 2 : 1)) void trmm_reduce_kernel(GpConst<NS, D> gc, BigWs ws, int64_t p128,
+                                                                      int row_tiles, int xcd_aware) {
+    extern __shared__ __attribute__((aligned(16))) double big_smem[];
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    lds_v2d* const lds = (lds_v2d*)big_smem;                 // [NBUF][2][8][PPC][64]
+    constexpr int kFrags = kBigRb * PPC;                      // fragments of one operand per chunk
+    constexpr int kPieces = 2 * kFrags / 4;                   // DMA pieces per wave and chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int pg = blockIdx.x, rt = blockIdx.y, d = blockIdx.z;
+    const int pgroups = (int)(p128 / kBigTile);
+    // XCD-aware decode (see above); any grid whose size is not a multiple of 8 keeps the plain order
+    int id = blockIdx.x;
+    const int total = gridDim.x;
+    int rt, pg, d;
+    if (xcd_aware & 8) {
+        // longest first: row tile rt does (rt + 1) / row_tiles of the longest tile's work, so the tiles are dealt out in
+        // descending rt (particle group fastest: the workgroups that run together share their W row tile through L2)
+        pg = id % pgroups;
+        d = (id / pgroups) % NS;
+        rt = row_tiles - 1 - id / (pgroups * NS);
+    } else {
+        if ((xcd_aware & 1) && (total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+        rt = id % row_tiles;
+        pg = (id / row_tiles) % pgroups;
+        d = id / (row_tiles * pgroups);
+    }
+    const int pg_src = (xcd_aware & 2) ? 0 : pg;     // (diagnostic, timing only: every workgroup reads particle group 0's Kstar)
+    const int rt_src = (xcd_aware & 4) ? 0 : rt;     // (diagnostic, timing only: every workgroup reads row tile 0's W)
     const int nrb = gc.n_pad >> 4;
     const int rb0 = rt * kBigRb;
     const int rb_end = (rb0 + kBigRb < nrb) ? rb0 + kBigRb : nrb;   // exclusive
     const int npairs = 2 * rb_end;                                   // K extent of the tile's longest row-block
+    const int nchunks = (npairs + PPC - 1) / PPC;
     const int64_t wpo = w_pairs_per_output(nrb);
-    const v2d* apack = reinterpret_cast<const v2d*>(gc.a_pack) + (int64_t)d * wpo * 64;
-    const int64_t tstride = (int64_t)(gc.n_pad >> 3) * 64;           // v2d per particle tile
-    const v2d* ks = reinterpret_cast<const v2d*>(ws.ks) + ((int64_t)d * (p128 / 16) + (int64_t)pg * kBigRb) * tstride;
+    const int64_t tstride = (int64_t)(gc.n_pad >> 3) * 64;           // 16-byte elements per particle tile
+
+    // buffer descriptors: W of output d (reads beyond it return 0), the 8 Kstar particle tiles of this workgroup
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(gc.a_pack) + (int64_t)d * wpo * 128, 0, (int)(wpo * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
+        ws.ks + (((int64_t)d * (p128 / 16) + (int64_t)pg_src * kBigRb) * tstride) * 2, 0, (int)(kBigRb * tstride * 16), 0x00020000);
+    // this wave's DMA pieces of a chunk: waves 0, 1 fetch the W fragments, waves 2, 3 the Kstar fragments;
+    // piece i = fragment f = kPieces (wave & 1) + i -> (block f / PPC, pair f % PPC)
+    const bool is_k = wave >= 2;
+    int piece_off[kPieces];     // byte offset of the fragment at q0 = 0 (SGPRs)
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+        const int f = kPieces * (wave & 1) + i, blk = f / PPC, pr = f % PPC;
+        const int rb = rt_src * kBigRb + blk;
+        piece_off[i] = is_k ? (int)((blk * tstride + pr * 64) * 16) : (rb * (rb + 1) + pr) * 1024;
+    }
+    const int lane16 = lane * 16;
+    auto issue_chunk = [&](int chunk, int buf) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int f = kPieces * (wave & 1) + i;
+            lds_v2d* dst = lds + ((buf * 2 + (is_k ? 1 : 0)) * kFrags + f) * 64;      // 1 KB per fragment
+            const int soff = piece_off[i] + chunk * (PPC * 1024);
+            if (is_k)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (__attribute__((address_space(3))) void*)dst, 16, lane16, soff, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)dst, 16, lane16, soff, 0, 0);
+        }
+    };
 
     v4d acc[4][4];
 #pragma unroll
@@ -170,44 +242,21 @@ __global__ __launch_bounds__(kBigThreads) void trmm_reduce_kernel(GpConst<NS, D>
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
 
-    // Global -> register -> LDS staging, one chunk (2 fragment pairs = 16 k) ahead: the loads of chunk c + 1 are in
-    // flight while the 32 MFMAs per wave of chunk c run.  A chunk is 8 row-blocks x 2 pairs of W and 8 particle tiles
-    // x 2 pairs of Kstar: 2 x 1024 v2d, 4 + 4 per thread.
-    v2d ra[4], rb_[4];
-    auto fetch = [&](int q0) {
+    auto compute = [&](int chunk, int buf) {
+        const lds_v2d* sa = lds + (buf * 2 + 0) * kFrags * 64 + lane;
+        const lds_v2d* sb = lds + (buf * 2 + 1) * kFrags * 64 + lane;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = it * kBigThreads + tid;   // 0 .. 1023
-            const int blk = idx >> 7, pr = (idx >> 6) & 1, ln = idx & 63;
-            const int rb = rb0 + blk, q = q0 + pr;
-            ra[it] = v2d{0.0, 0.0};
-            if (rb < rb_end && q < 2 * (rb + 1)) ra[it] = apack[((int64_t)rb * (rb + 1) + q) * 64 + ln];
-            rb_[it] = ks[(int64_t)blk * tstride + (int64_t)q * 64 + ln];
-        }
-    };
-    fetch(0);
-    for (int q0 = 0; q0 < npairs; q0 += 2) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = it * kBigThreads + tid;
-            const int blk = idx >> 7, pr = (idx >> 6) & 1, ln = idx & 63;
-            sA[blk][pr][ln] = ra[it];
-            sB[blk][pr][ln] = rb_[it];
-        }
-        __syncthreads();
-        if (q0 + 2 < npairs) fetch(q0 + 2);
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
+        for (int pr = 0; pr < PPC; ++pr) {
             v2d a[4], b[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = sA[4 * wr + m][pr][lane];
+            for (int m = 0; m < 4; ++m) a[m] = sa[((4 * wr + m) * PPC + pr) * 64];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = sB[4 * wc + n][pr][lane];
+            for (int n = 0; n < 4; ++n) b[n] = sb[((4 * wc + n) * PPC + pr) * 64];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                // beyond the diagonal of row-block rb0 + 4 wr + m its W fragments are zero padding: nothing to add
+                // beyond the diagonal of row-block rb0 + 4 wr + m its W fragments are not its own: nothing to add
                 // (wave-uniform; only the last chunks of a tile's K extent are affected)
-                if (q0 + pr >= 2 * (rb0 + 4 * wr + m + 1)) continue;
+                if (chunk * PPC + pr >= 2 * (rb0 + 4 * wr + m + 1)) continue;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
@@ -215,7 +264,33 @@ __global__ __launch_bounds__(kBigThreads) void trmm_reduce_kernel(GpConst<NS, D>
                 }
             }
         }
-        __syncthreads();
+    };
+
+    // Pipeline: NBUF - 1 chunks of DMA in flight.  Iteration c: wait until this wave's pieces of chunk c have landed (all
+    // but the NBUF - 2 younger chunks' pieces), barrier -- now chunk c is in LDS for everyone and everyone is done reading
+    // buffer (c - 1) % NBUF --, refill that buffer with chunk c + NBUF - 1, compute chunk c.  The barrier is a raw
+    // s_barrier: __syncthreads() would drain the DMA in flight (vmcnt(0)).
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c)
+        if (c < nchunks) issue_chunk(c, c);
+    auto step = [&](int c, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        // outstanding after this wait: the pieces of the chunks younger than c that have been issued
+        const int younger = (nchunks - 1 - c) < (NBUF - 2) ? (nchunks - 1 - c) : (NBUF - 2);
+        if (younger >= 1 && NBUF >= 3)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + NBUF - 1 < nchunks) issue_chunk(c + NBUF - 1, (BUF + NBUF - 1) % NBUF);
+        compute(c, BUF);
+    };
+    static_assert(NBUF == 2 || NBUF == 3, "the wait counts are written for one or two chunks in flight");
+    for (int c = 0; c < nchunks; c += NBUF) {
+        step(c, std::integral_constant<int, 0>{});
+        if (c + 1 < nchunks) step(c + 1, std::integral_constant<int, 1>{});
+        if (NBUF == 3 && c + 2 < nchunks) step(c + 2, std::integral_constant<int, 2 % NBUF>{});
     }
     // epilogue: rows < N are squared and summed, rows N .. N + D are the mean / Jacobian rows
 #pragma unroll
@@ -237,7 +312,7 @@ __global__ __launch_bounds__(kBigThreads) void trmm_reduce_kernel(GpConst<NS, D>
         }
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (lane < 16) ws.part[((int64_t)d * gridDim.y * 2 + rt * 2 + wr) * p128 + p] = s;
+        if (lane < 16) ws.part[((int64_t)d * row_tiles * 2 + rt * 2 + wr) * p128 + p] = s;
     }
 }
 

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -421,6 +422,39 @@ static int launch_polytope(const sx_env* env, int P, const double* p, const doub
     return check_launch();
 }
 
+// trmm_reduce_kernel variants, selectable for A/B measurements (tools/cfg4_probe.py):
+//   SX_TRMM_ORDER   = tile order bits: 8 longest-first (default), 1 XCD-contiguous with the row tile fastest, 0 plain;
+//                     + 2 / + 4: timing-only diagnostics (every workgroup reads the same Kstar / W tile: no fabric traffic)
+//   SX_TRMM_VARIANT = <pairs per chunk><LDS buffers>: 13 (default), 12, 22, 23
+// Measured at config 4 (N = 2000, 16 384 particles), per launch: plain order 7.2 ms, XCD-contiguous 4.73 ms, longest-first
+// 3.92 ms -- whatever the variant, and the same with the fabric traffic removed (order + 6): the kernel was never
+// memory-bound, its tiles differ 16-fold in work and the tail of the launch was what it lost.
+static const int g_trmm_xcd_aware = std::getenv("SX_TRMM_ORDER") ? std::atoi(std::getenv("SX_TRMM_ORDER")) : 8;
+static const int g_trmm_variant = std::getenv("SX_TRMM_VARIANT") ? std::atoi(std::getenv("SX_TRMM_VARIANT")) : 13;
+
+template <int NS, int D, int PPC, int NBUF>
+static void launch_trmm_v(int kind, const GpConst<NS, D>& gc, const BigWs& ws, int64_t p128, int row_tiles, hipStream_t stream) {
+    constexpr int lds = big_lds_bytes<PPC, NBUF>();
+    (void)allow_lds(trmm_reduce_kernel<NS, D, PPC, NBUF>, lds);
+    const dim3 grid((unsigned)((p128 / kBigTile) * row_tiles * NS));
+    if (kind >= 0)
+        launch(kind, trmm_reduce_kernel<NS, D, PPC, NBUF>, grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles,
+               g_trmm_xcd_aware);
+    else
+        hipLaunchKernelGGL((trmm_reduce_kernel<NS, D, PPC, NBUF>), grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles,
+                           g_trmm_xcd_aware);
+}
+
+template <int NS, int D>
+static void launch_trmm(int kind, const GpConst<NS, D>& gc, const BigWs& ws, int64_t p128, int row_tiles, hipStream_t stream) {
+    switch (g_trmm_variant) {
+        case 12: return launch_trmm_v<NS, D, 1, 2>(kind, gc, ws, p128, row_tiles, stream);
+        case 22: return launch_trmm_v<NS, D, 2, 2>(kind, gc, ws, p128, row_tiles, stream);
+        case 23: return launch_trmm_v<NS, D, 2, 3>(kind, gc, ws, p128, row_tiles, stream);
+        default: return launch_trmm_v<NS, D, 1, 3>(kind, gc, ws, p128, row_tiles, stream);
+    }
+}
+
 // ---- sx_gp_predict for training sets beyond the LDS budget: the same Kstar / triangular-product kernels, then collect ----
 template <int NS, int D>
 __global__ void predict_init_big_kernel(const double* __restrict__ z, int64_t P, int64_t p128, BigWs ws) {
@@ -463,8 +497,7 @@ static int launch_predict_big(const sx_gp_model* m, const double* z, int P, doub
                        (int64_t)P, p128, ws);
     hipLaunchKernelGGL((kstar_big_kernel<NS, D>), dim3((unsigned)(p128 / 16), (unsigned)((m->n_pad + 255) / 256)), dim3(256),
                        0, stream, gc, ws);
-    hipLaunchKernelGGL((trmm_reduce_kernel<NS, D>), dim3((unsigned)(p128 / kBigTile), (unsigned)row_tiles, NS),
-                       dim3(kBigThreads), 0, stream, gc, ws, p128);
+    launch_trmm<NS, D>(-1, gc, ws, p128, row_tiles, stream);
     hipLaunchKernelGGL((predict_collect_big_kernel<NS, D>), dim3((unsigned)((P + 63) / 64)), dim3(64), 0, stream, gc, ws,
                        (int64_t)P, p128, row_tiles * 2, mean, var, jac);
     return check_launch();
@@ -478,6 +511,7 @@ static bool fused_fits(int ns, int nu, int n_train, int n_pad, int H, int ns_lds
         (gp_tile_lds_doubles(ns, ns + nu, n_train, n_pad, nw, ns_lds) + (size_t)SX_TILE * H * nu) * sizeof(double);
     return lds <= kMaxLdsBytes && n_pad <= 1024;
 }
+
 
 template <int NS, int NU>
 static int launch_rollout_big(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, double* workspace,
@@ -499,8 +533,7 @@ static int launch_rollout_big(const sx_gp_model* m, const sx_env* env, const Rol
     for (int t = 0; t < rp.H; ++t) {
         launch(SX_PROF_KSTAR_BIG, kstar_big_kernel<NS, D>, dim3((unsigned)(p128 / 16), (unsigned)((m->n_pad + 255) / 256)),
                dim3(256), 0, stream, gc, ws);
-        launch(SX_PROF_TRMM_BIG, trmm_reduce_kernel<NS, D>, dim3((unsigned)(p128 / kBigTile), (unsigned)row_tiles, NS),
-               dim3(kBigThreads), 0, stream, gc, ws, p128);
+        launch_trmm<NS, D>(SX_PROF_TRMM_BIG, gc, ws, p128, row_tiles, stream);
         BigStep bs{rp.actions, rp.traj, rp.sigma, rp.obj_cost, rp.con_cost, rp.status, rp.H, t, row_tiles * 2,
                    (t > 0 || rp.q0 != nullptr) ? 1 : 0};
         launch(SX_PROF_STEP_BIG, step_big_kernel<NS, NU>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, stream, gc, rc, cc,

@@ -242,30 +242,60 @@ def main():
         E, total_particles, solver_group = per_gpu, P, None
         x0 = torch.tensor(w.x0[rank * per_gpu:(rank + 1) * per_gpu], dtype=torch.float64, device=dev)
     init_std = w.init_std if np.ndim(w.init_std) == 0 else np.asarray(w.init_std)[:H]
-    mpc = FusedCemMpc(ssm, env, H, total_particles, elites, iters, device=dev, seed=1, init_std=init_std,
-                      warm_start='safe_policy' if w.warm_start != 'zero' else 'zero', process_group=solver_group)
+    lib = _lib.lib()
 
     def barrier():
         if world > 1:
             dist.barrier(group)
         torch.cuda.synchronize(dev)
 
-    for _ in range(warmup):
-        mpc.solve(x0)
-    lib = _lib.lib()
-    if not args.no_kernel_timer:
-        # HIP events on every 4th launch of each kernel (every launch of the large-N path, whose kernels run for
-        # milliseconds): timing every 130 us launch costs the solve ~7 % (measured), every 4th < 2 %
-        _lib.check(lib.sx_profile_stride(1 if w.cfg == 4 else 4), 'sx_profile_stride')
-        _lib.check(lib.sx_profile_enable(max(4096, steps * iters * (3 * H + 4))), 'sx_profile_enable')
-    if world > 1 and w.sharded:
-        mpc.exchange_events = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        best, ok, _, status = mpc.solve(x0)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def start_timer():
+        if not args.no_kernel_timer:
+            # HIP events on every 4th launch of each kernel (every launch of the large-N path, whose kernels run for
+            # milliseconds): timing every 130 us launch costs the solve ~7 % (measured), every 4th < 2 %
+            _lib.check(lib.sx_profile_stride(1 if w.cfg == 4 else 4), 'sx_profile_stride')
+            _lib.check(lib.sx_profile_enable(max(4096, steps * iters * (3 * H + 4))), 'sx_profile_enable')
+
+    if w.cfg == 5:
+        # config 5 runs through the product's own multi-episode driver: E episodes in lockstep over stub environments
+        # (episode_runner.do_rollout_batch -> CemSafeMPC.get_action_batch -> one fused solve per step, the per-episode
+        # fallback ladders and the one device->host hand-off per step included); 1 step = 1 lockstep step
+        from safe_exploration_amd.episode_runner import do_rollout_batch
+
+        class Conf:
+            mpc_time_horizon, cem_num_rollouts, cem_num_elites, cem_num_iterations, cem_init_std = H, P, elites, iters, init_std
+            device, use_state_constraint, use_prior_model = str(dev), True, True
+            exact_gp_training_iterations, exact_gp_kernel, cem_seed = 0, 'rbf', 1
+            plot_cem_optimisation = plot_cem_terminal_states = False
+
+        envs = [problems.StubEnv(spec, x, never_done=True) for x in x0.cpu().numpy()]
+        solver, _ = problems.make_solver(spec, Conf(), envs[0], dev)
+        mpc = solver._solver()
+        do_rollout_batch(envs, warmup, solver)
+        start_timer()
+        barrier()
+        t0 = time.perf_counter()
+        episodes = do_rollout_batch(envs, steps, solver)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        status = torch.tensor([mpc.last_status], dtype=torch.int32)
+        from safe_exploration_amd.safempc_cem import MpcResult
+        ok = torch.tensor([int(any(MpcResult.FOUND_SOLUTION in r.mpc_results for r in episodes))])
+        assert all(r.episode_length == steps for r in episodes)
+    else:
+        mpc = FusedCemMpc(ssm, env, H, total_particles, elites, iters, device=dev, seed=1, init_std=init_std,
+                          warm_start='safe_policy' if w.warm_start != 'zero' else 'zero', process_group=solver_group)
+        for _ in range(warmup):
+            mpc.solve(x0)
+        start_timer()
+        if world > 1 and w.sharded:
+            mpc.exchange_events = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            best, ok, _, status = mpc.solve(x0)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -310,7 +340,8 @@ def main():
                            'baseline_config': w.cfg, 'particles_per_gpu': P, 'episodes_per_gpu': E, 'horizon': H,
                            'n_train': n_train, 'cem_iterations': iters, 'elites': elites, 'warm_start': w.warm_start,
                            'parallelism': (f'particle-sharded x{world}, 1 all-reduce/iteration' if w.sharded
-                                           else f'episodes striped x{world}, no collective'),
+                                           else f'episodes striped x{world}, no collective; lockstep runner '
+                                                f'(episode_runner.do_rollout_batch)'),
                            'backend': args.backend if world > 1 else None},
                 'mpc_solves_per_s': steps * episodes_total / elapsed,
                 'particle_rollouts_per_s': particle_steps / H / elapsed,

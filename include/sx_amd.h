@@ -151,6 +151,13 @@ int sx_gp_predict(const sx_gp_model* model, const double* z, int P, double* mean
 int sx_gp_predict_var_jac(const sx_gp_model* model, const double* linv, const double* z, int P, double* jac_var,
                           void* stream);
 
+/* d^2 mean / dz dz^T at z dev [P x D]: hess dev [P x n_s x D x D] (symmetric); `alpha` dev [n_s x N] as produced by sx_gp_fit.
+ * Not on the CEM path: it completes the numpy adapter's linearize_predict / get_linearize_reverse, which the casadi
+ * callback of the reference's other solvers consumes (state_space_models.py:279-304).  Replaces:
+ * GPyTorchSSM._compute_hessian_mean (ssm_pytorch/gaussian_process.py:160-187, the `hessian` package over autograd). */
+int sx_gp_predict_mean_hessian(const sx_gp_model* model, const double* alpha, const double* z, int P, double* hess,
+                               void* stream);
+
 /* Bytes of workspace sx_gp_predict needs (0 while the training set fits the single-launch kernel; < 0 = bad arguments). */
 int64_t sx_gp_predict_workspace_bytes(const sx_gp_model* model, int P);
 

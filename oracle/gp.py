@@ -77,6 +77,18 @@ class ExactGP:
             out[:, d, :] = 2.0 * (w.sum(1)[:, None] * z - w @ self.X) / (self.ls[d] ** 2)[None, :]
         return out
 
+    def mean_hessian(self, z):
+        """d^2 mean_d / dz dz^T = sum_i alpha_i k_i [g_i g_i^T - diag(1 / l_d^2)], g_i = (z - X_i) / l_d^2   [P x n_s x D x D].
+        (The reference gets it from the `hessian` package over autograd, ssm_pytorch/gaussian_process.py:160-187; closed
+        form here, pinned by finite differences of `predict`'s Jacobian in tests/test_oracle_golden.py.)"""
+        z = np.asarray(z, dtype=np.float64)
+        out = np.empty((z.shape[0], self.n_s, self.D, self.D))
+        for d in range(self.n_s):
+            w = self.kernel(d, z, self.X) * self.alpha[d][None, :]                 # [P x N]
+            g = (z[:, None, :] - self.X[None, :, :]) / (self.ls[d] ** 2)[None, None, :]   # [P x N x D]
+            out[:, d] = np.einsum('pi,pij,pil->pjl', w, g, g) - w.sum(1)[:, None, None] * np.diag(1.0 / self.ls[d] ** 2)[None]
+        return out
+
     # the operands the HIP kernels consume (checked against the device-side fit in tests)
     def linv(self):
         """[n_s x N x N] inverse Cholesky factors W_d = L_d^-1 (lower triangular)."""

@@ -56,6 +56,7 @@ SIGNATURES = {
                               c_void_p]),
     'sx_gp_predict_workspace_bytes': (c_int64, [POINTER(SxGpModel), c_int]),
     'sx_gp_predict_var_jac': (c_int, [POINTER(SxGpModel), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'sx_gp_predict_mean_hessian': (c_int, [POINTER(SxGpModel), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'sx_onestep_reach': (c_int, [POINTER(SxEnv), c_int] + [c_void_p] * 11),
     'sx_polytope_distance': (c_int, [POINTER(SxEnv), c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p,
                                      c_void_p]),

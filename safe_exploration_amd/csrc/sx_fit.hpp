@@ -346,4 +346,67 @@ __global__ __launch_bounds__(256) void gp_var_jac_kernel(VarJacArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// sx_gp_predict_mean_hessian: d^2 mean_d / dz dz^T for the numpy StateSpaceModel adapter's linearize_predict (the
+// reference differentiates gpytorch's mean twice with autograd: ssm_pytorch/gaussian_process.py:160-187).
+//     mean_d(z) = sum_i alpha_di k_i(z),   k_i = s_d exp(-1/2 sum_j (z_j - X_ij)^2 / l_dj^2)
+//     H_d[j][l] = sum_i alpha_di k_i [ (z_j - X_ij)(z_l - X_il) / (l_dj^2 l_dl^2) - delta_jl / l_dj^2 ]
+// One workgroup per (query point, output); a thread per training point, D (D + 1) / 2 sums reduced through LDS in a fixed
+// order (results do not depend on scheduling).
+// ---------------------------------------------------------------------------------------------------------------
+struct MeanHessArgs {
+    double inv_ls2[SX_MAX_NS * SX_MAX_D];
+    double outputscale[SX_MAX_NS];
+    const double* x;      // [N x D]
+    const double* alpha;  // [n_s x N]
+    const double* z;      // [P x D]
+    double* hess;         // [P x n_s x D x D]
+    int n, D, n_s;
+};
+
+__global__ __launch_bounds__(256) void gp_mean_hessian_kernel(MeanHessArgs a) {
+    constexpr int kPairs = SX_MAX_D * (SX_MAX_D + 1) / 2;
+    __shared__ double red[4][kPairs];
+    const int p = blockIdx.x, d = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n, D = a.D;
+    double z[SX_MAX_D], w2[SX_MAX_D], acc[kPairs];
+    for (int j = 0; j < D; ++j) {
+        z[j] = a.z[(size_t)p * D + j];
+        w2[j] = a.inv_ls2[d * D + j];
+    }
+    for (int c = 0; c < kPairs; ++c) acc[c] = 0.0;
+    for (int i = tid; i < n; i += blockDim.x) {
+        double q = 0.0, g[SX_MAX_D];
+        for (int j = 0; j < D; ++j) {
+            const double df = z[j] - a.x[(size_t)i * D + j];
+            q += df * df * w2[j];
+            g[j] = df * w2[j];
+        }
+        const double ak = a.alpha[(size_t)d * n + i] * a.outputscale[d] * exp(-0.5 * q);
+        int c = 0;
+        for (int j = 0; j < D; ++j)
+            for (int l = j; l < D; ++l, ++c) acc[c] += ak * (g[j] * g[l] - (j == l ? w2[j] : 0.0));
+    }
+    const int npairs = D * (D + 1) / 2;
+    for (int c = 0; c < npairs; ++c) {
+        double s = acc[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) red[wave][c] = s;
+    }
+    __syncthreads();
+    if (tid < npairs) {
+        const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        int c = 0;
+        for (int j = 0; j < D; ++j)
+            for (int l = j; l < D; ++l, ++c)
+                if (c == tid) {
+                    double* h = a.hess + ((size_t)p * a.n_s + d) * D * D;
+                    h[j * D + l] = s;
+                    h[l * D + j] = s;
+                }
+    }
+}
+
 }  // namespace sx

@@ -805,6 +805,29 @@ int sx_gp_predict_var_jac(const sx_gp_model* model, const double* linv, const do
     return sx::check_launch();
 }
 
+int sx_gp_predict_mean_hessian(const sx_gp_model* model, const double* alpha, const double* z, int P, double* hess,
+                               void* stream) {
+    if (!model || P < 0) return SX_ERR_ARG;
+    if (P == 0) return SX_OK;
+    if (!model->x_train || !alpha || !z || !hess) return SX_ERR_ARG;
+    if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)
+        return SX_ERR_ARG;
+    sx::MeanHessArgs ha;
+    std::memset(&ha, 0, sizeof(ha));
+    const int D = model->n_s + model->n_u;
+    for (int i = 0; i < model->n_s * D; ++i) ha.inv_ls2[i] = model->inv_ls2[i];
+    for (int i = 0; i < model->n_s; ++i) ha.outputscale[i] = model->outputscale[i];
+    ha.x = model->x_train;
+    ha.alpha = alpha;
+    ha.z = z;
+    ha.hess = hess;
+    ha.n = model->n_train;
+    ha.D = D;
+    ha.n_s = model->n_s;
+    hipLaunchKernelGGL(sx::gp_mean_hessian_kernel, dim3(P, model->n_s), dim3(256), 0, (hipStream_t)stream, ha);
+    return sx::check_launch();
+}
+
 int sx_gp_pack(sx_gp_model* model, const double* linv, const double* alpha, void* stream) {
     if (!model || !linv || !alpha || !model->x_train || !model->a_pack || !model->stage_tab) return SX_ERR_ARG;
     if (model->n_s <= 0 || model->n_s > SX_MAX_NS || model->n_u <= 0 || model->n_u > SX_MAX_NU || model->n_train <= 0)

@@ -244,3 +244,68 @@ def baseline_workload(cfg: int, n_gpus: int = 1, n_train: Optional[int] = None) 
         return Workload(5, 'cfg5 batched exploration', spec, 15, 4096, 409, 8, 0.1, 'zero', start_states(2, 8 * n_gpus),
                         sharded=False, notes='8 independent episodes per GPU x 4096 particles, one fused solve')
     raise ValueError(f'BASELINE.json has configs 1..5, got {cfg}')
+
+
+class StubEnv:
+    """The attributes and methods the solver and the lockstep runner read from an ``Environment`` (reference
+    ``environments.py:44-400``), filled from a ProblemSpec.  The "true system" is the linear prior (the simulators are the
+    reference's host code and stay out of scope); an episode is `done` when the state leaves the safe polytope."""
+
+    def __init__(self, spec: ProblemSpec, x0, never_done: bool = False, objective_target: Optional[float] = None):
+        self.spec = spec
+        self.n_s, self.n_u = spec.n_s, spec.n_u
+        self.l_mu, self.l_sigm = spec.l_mu, spec.l_sigma
+        self.u_min_norm, self.u_max_norm = spec.u_min, spec.u_max
+        self._x0 = np.asarray(x0, dtype=np.float64).copy()
+        self._never_done = never_done
+        self._current_objective = objective_target
+        self.state = self._x0.copy()
+        self.steps = 0
+
+    def reset(self, mean=None, std=None):
+        self.state = self._x0.copy() if mean is None else np.asarray(mean, dtype=np.float64).copy()
+        self.steps = 0
+        return self.state.copy()
+
+    def random_action(self):
+        return np.zeros(self.n_u)
+
+    def step(self, action):
+        """-> (applied action, next state, observation, done, env_result) like Environment.step (environments.py:95-120)."""
+        action = np.clip(np.asarray(action, dtype=np.float64).reshape(self.n_u), self.spec.u_min, self.spec.u_max)
+        self.state = self.spec.a @ self.state + self.spec.b @ action
+        self.steps += 1
+        outside = bool((self.spec.h_mat @ self.state > self.spec.h_vec.reshape(-1)).any())
+        done = outside and not self._never_done
+        return action, self.state.copy(), self.state.copy(), done, (1 if outside else 0)
+
+    def objective_cost_function(self, ps):
+        if self._current_objective is None:
+            return None
+        import torch
+        return torch.abs(torch.full_like(ps[:, 1], self._current_objective) - ps[:, 1])
+
+    def get_safety_constraints(self, normalize=True):
+        return self.spec.h_mat, self.spec.h_vec, None, None
+
+    def collect_metrics(self):
+        return {'stub_env_steps': self.steps}
+
+
+def make_solver(spec: ProblemSpec, conf, env=None, device='cuda:0'):
+    """A ``CemSafeMPC`` over the spec's GP and constants, the way ``utils_config.create_solver``'s ``safempc_cem`` branch
+    builds it (reference utils_config.py:116-121): (solver, env)."""
+    from .safempc_cem import CemSafeMPC, construct_constraints
+    from .ssm_cem.gp_ssm_cem import GpCemSSM
+    env = env if env is not None else StubEnv(spec, np.zeros(spec.n_s))
+    ssm = GpCemSSM(conf, spec.n_s, spec.n_u)
+    ssm.set_hyperparameters(spec.lengthscale, spec.outputscale, spec.noise)
+    q_lqr = np.diag([1.0, 2.0]) if spec.n_s == 2 else np.diag([2.0, 6.0, 12.0, 4.0])[:spec.n_s, :spec.n_s]
+    r_lqr = (25.0 if spec.n_s == 2 else 40.0) * np.eye(spec.n_u)
+    solver = CemSafeMPC(ssm, construct_constraints(conf, env), env, conf, {'lin_model': (spec.a, spec.b)},
+                        wx_feedback_cost=q_lqr, wu_feedback_cost=r_lqr, beta_safety=spec.beta,
+                        safe_policy=lambda x: spec.k_fb @ x)
+    # update_model subtracts the prior, so hand it y + prior to end up with the spec's targets
+    y = spec.Y + spec.X[:, :spec.n_s] @ spec.a.T + spec.X[:, spec.n_s:] @ spec.b.T
+    solver.update_model(spec.X, y, opt_hyp=False, replace_old=True)
+    return solver, env

@@ -311,15 +311,22 @@ class CemSafeMPC(SafeMPC):
             result = MpcResult.SAFE_CONTROLLER
         return action, result
 
-    def get_action_batch(self, states: ndarray) -> Tuple[ndarray, List[MpcResult]]:
-        """``get_action`` for E independent episodes in lockstep (BASELINE config 5): states [E x n_s] ->
-        (actions [E x n_u], one MpcResult per episode).  One fused solve serves all episodes; each episode keeps its own
-        PREVIOUS_SOLUTION / SAFE_CONTROLLER ladder (reference safempc_cem.py:243-263).  The episode count is fixed by the
-        first call (``reset_batch`` starts over)."""
+    def get_action_batch(self, states: ndarray, episode_ids=None, num_episodes: Optional[int] = None
+                         ) -> Tuple[ndarray, List[MpcResult]]:
+        """``get_action`` for independent episodes in lockstep (BASELINE config 5): states [A x n_s] ->
+        (actions [A x n_u], one MpcResult per row).  One fused solve serves all rows; each episode keeps its own
+        PREVIOUS_SOLUTION / SAFE_CONTROLLER ladder (reference safempc_cem.py:243-263).  `episode_ids` names the episode
+        of each row (default 0 .. A-1) out of `num_episodes` -- a lockstep runner passes the episodes that are still
+        running, and their ladders carry on where they were.  The ladder state is allocated by the first call and
+        whenever `num_episodes` changes (``reset_batch`` starts over)."""
         states = np.asarray(states)
         if states.ndim != 2 or states.shape[1] != self._state_dimen:
             raise ValueError(f'Wanted shape (E, {self._state_dimen}), got {states.shape}')
-        E = states.shape[0]
+        A = states.shape[0]
+        ids = list(range(A)) if episode_ids is None else [int(e) for e in episode_ids]
+        E = int(num_episodes) if num_episodes is not None else max(max(ids) + 1, A)
+        if len(ids) != A or len(set(ids)) != A or min(ids) < 0 or max(ids) >= E:
+            raise ValueError(f'episode_ids must name {A} distinct episodes out of {E}, got {ids}')
         if self._batch_last_actions is None or len(self._batch_last_actions) != E:
             self._batch_last_actions = [np.empty((0, self.action_dimen)) for _ in range(E)]
             self._batch_executed = [0] * E
@@ -329,18 +336,18 @@ class CemSafeMPC(SafeMPC):
         self.last_rollouts = rollouts
         actions: List[ndarray] = []
         results: List[MpcResult] = []
-        for e in range(E):
-            if bool(found[e]):
-                self._batch_last_actions[e] = best[e]
+        for k, e in enumerate(ids):
+            if bool(found[k]):
+                self._batch_last_actions[e] = best[k]
                 self._batch_executed[e] = 1
-                actions.append(best[e][0])
+                actions.append(best[k][0])
                 results.append(MpcResult.FOUND_SOLUTION)
             elif self._batch_executed[e] < self._batch_last_actions[e].shape[0]:
                 actions.append(self._batch_last_actions[e][self._batch_executed[e]])
                 self._batch_executed[e] += 1
                 results.append(MpcResult.PREVIOUS_SOLUTION)
             else:
-                actions.append(np.asarray(self._safe_policy(states[e])))
+                actions.append(np.asarray(self._safe_policy(states[k])))
                 results.append(MpcResult.SAFE_CONTROLLER)
         return np.stack(actions), results
 

@@ -264,6 +264,21 @@ class GpCemSSM(CemSSM):
                                                    _lib.ptr(out), _lib.stream_ptr(z.device)), 'sx_gp_predict_var_jac')
         return out
 
+    def predict_mean_hessian(self, states: Tensor, actions: Tensor) -> Tensor:
+        """d^2 mean / d(state, action)^2  [N x n_s x (n_s + n_u) x (n_s + n_u)] (closed form, sx_gp_predict_mean_hessian).
+        Not used by the CEM solver; the numpy adapter's linearize_predict returns it where the reference's GPyTorchSSM
+        calls the `hessian` package (ssm_pytorch/gaussian_process.py:160-187)."""
+        z = self._join_states_actions(states, actions)
+        n, d_in = z.size(0), self.num_states + self.num_actions
+        _lib.require_gpu(z, 'states/actions')
+        z = z.detach().contiguous()
+        out = torch.zeros((n, self.num_states, d_in, d_in), dtype=torch.float64, device=z.device)
+        if n == 0 or self._model is None:   # the prior mean is flat
+            return out
+        _lib.check(_lib.lib().sx_gp_predict_mean_hessian(ctypes.byref(self._model), _lib.ptr(self._alpha), _lib.ptr(z), n,
+                                                        _lib.ptr(out), _lib.stream_ptr(z.device)), 'sx_gp_predict_mean_hessian')
+        return out
+
     def predict_raw(self, z: Tensor) -> Tuple[Tensor, Tensor]:
         mean, var, _ = self._predict_z(z, False)
         return mean.t(), var.t()

@@ -362,6 +362,39 @@ def test_numpy_state_space_model_adapter():
     assert m2.shape == (1, 4) and np.array_equal(m2, m[:1])
     with pytest.raises(NotImplementedError):
         model.predict(z[:, :4], z[:, 4:], full_cov=True)
+    # linearize_predict / get_reverse / get_linearize_reverse (reference ssm_pytorch/gaussian_process.py:270-336): what
+    # CasadiSSMEvaluator asks of a model with linearize_mu=True (state_space_models.py:279-304)
+    assert model.has_reverse and model.has_jacobian
+    lm, lv, lj = model.linearize_predict(z[:, :4], z[:, 4:])
+    np.testing.assert_array_equal(lm, m)
+    np.testing.assert_array_equal(lj, j)
+    with pytest.raises(NotImplementedError):
+        model.linearize_predict(z[:, :4], z[:, 4:], jacobians=True)             # second-order outputs: single inputs only
+    lm1, lv1, lj1, ljv1, hess = model.linearize_predict(z[:1, :4], z[:1, 4:], jacobians=True)
+    assert hess.shape == (4, 5, 5)
+    np.testing.assert_allclose(hess, gp.mean_hessian(z[:1])[0], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ssm.predict_mean_hessian(T(z[:, :4]), T(z[:, 4:])).cpu().numpy(), gp.mean_hessian(z),
+                               rtol=1e-9, atol=1e-12)
+    seed = rng.normal(size=(2 * 4 + 4 * 5, 1))
+    gs, ga = model.get_linearize_reverse(seed)
+    want = jo[0].T @ seed[:4, 0] + gp.variance_jacobian(z[:1])[0].T @ seed[4:8, 0] \
+        + np.einsum('dj,djl->l', seed[8:, 0].reshape(4, 5), gp.mean_hessian(z[:1])[0])
+    assert gs.shape == (4, 1) and ga.shape == (1, 1)
+    np.testing.assert_allclose(np.concatenate((gs, ga))[:, 0], want, rtol=1e-8, atol=1e-12)
+    model.predict(z[2:5, :4], z[2:5, 4:])
+    seed2 = rng.normal(size=(8, 3))
+    gs2, ga2 = model.get_reverse(seed2)
+    want2 = jo[2].T @ seed2[:4, 0] + gp.variance_jacobian(z[2:3])[0].T @ seed2[4:, 0]
+    np.testing.assert_allclose(np.concatenate((gs2, ga2)), want2, rtol=1e-8, atol=1e-12)
+    # the reverse sweep is the transpose of the forward linearisation: a finite difference of seed . outputs agrees
+    eps = 1e-6
+    fd = np.empty(5)
+    for c in range(5):
+        dz = np.zeros((1, 5)); dz[0, c] = eps
+        mp, vp = model.predict((z[2:3] + dz)[:, :4], (z[2:3] + dz)[:, 4:])
+        mm, vm = model.predict((z[2:3] - dz)[:, :4], (z[2:3] - dz)[:, 4:])
+        fd[c] = (seed2[:4, 0] @ (mp - mm)[0] + seed2[4:, 0] @ (vp - vm)[0]) / (2 * eps)
+    np.testing.assert_allclose(want2, fd, rtol=1e-5, atol=1e-8)
 
 
 def test_mll_and_gradient_vs_autograd():

@@ -147,6 +147,14 @@ def test_gp_structure():
         _, vp, _ = gp2.predict(z + dz, False)
         _, vm, _ = gp2.predict(z - dz, False)
         np.testing.assert_allclose(jv[:, :, c], (vp - vm) / (2 * eps), rtol=1e-5, atol=1e-8)
+    hess = gp.mean_hessian(z)                              # mean Hessian: closed form == numeric, symmetric
+    assert hess.shape == (7, 2, 3, 3)
+    np.testing.assert_allclose(hess, hess.transpose(0, 1, 3, 2), rtol=1e-12, atol=1e-15)
+    for c in range(3):
+        dz = np.zeros(3); dz[c] = eps
+        _, _, jp = gp.predict(z + dz)
+        _, _, jm = gp.predict(z - dz)
+        np.testing.assert_allclose(hess[:, :, :, c], (jp - jm) / (2 * eps), rtol=1e-5, atol=1e-7)
 
 
 def test_action_constraint_known_answer():

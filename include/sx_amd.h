@@ -91,6 +91,40 @@ typedef struct sx_env {
 /* Library / build identification: returns "sxamd <version> gfx950". */
 const char* sx_version(void);
 
+/* ---- exact GPs with a degenerate kernel: 'linear' and 'nn' of ssm_cem/gp_ssm_cem.py:45-57,140-185 ----
+ * k_d(x, x') = c_d phi(x) . phi(x'), phi = identity (linear kernel) or a small fully connected network with the reference's
+ * per-point min/max normalisation (NNFeatureKernel).  Such a GP is Bayesian linear regression on F features: the kernels
+ * below work in weight space (A_d = Phi^T Phi + noise_d / c_d I, F x F), one particle per lane, no N x N operand. */
+#define SX_FEAT_MAX_WIDTH 32     /* widest layer / feature count F */
+#define SX_FEAT_MAX_LAYERS 3     /* linear layers of the feature network (0 = linear kernel) */
+typedef struct sx_feat_model {
+    int32_t n_s, n_u;
+    int32_t n_feat;              /* F: D for the linear kernel, the last layer's width otherwise */
+    int32_t n_layers;            /* 0 = phi(z) = z */
+    int32_t normalise;           /* 1 = phi = 2 (f - min f) / max f - 1 per point (gp_ssm_cem.py:176-181) */
+    int32_t width[SX_FEAT_MAX_LAYERS + 1];   /* width[0] = D, width[l] = outputs of layer l */
+    double prelu;                /* slope of the PReLU behind the last layer (ReLU between the layers) */
+    double noise[SX_MAX_NS];     /* likelihood noise, included in the predictive variance */
+    const double* net;           /* dev: per layer W_l [width[l] x width[l-1]] row-major, then b_l [width[l]] */
+    const double* wbar;          /* dev [n_s x F]      posterior weight means (sx_feat_fit) */
+    const double* minv;          /* dev [n_s x F x F]  M_d = chol(A_d)^-1, lower triangular (sx_feat_fit) */
+} sx_feat_model;
+
+/* phi dev [N x F] = phi(x dev [N x D]).  Uses model->{n_s,n_u,n_feat,n_layers,normalise,width,prelu,net}. */
+int sx_feat_features(const sx_feat_model* model, const double* x, int N, double* phi, void* stream);
+/* Weight-space fit from phi dev [N x F], y dev [N x n_s], lambda host [n_s] = noise_d / c_d:
+ * wbar dev [n_s x F], minv dev [n_s x F x F], stats dev [n_s x 3] = { y^T y, |M Phi^T y|^2, sum log diag chol(A) } (what the
+ * exact marginal likelihood needs), status dev int32 (SX_STATUS_NOT_PD).
+ * Replaces: gpytorch's ExactGP on set_train_data for these kernels (ssm_cem/gp_ssm_cem.py:96-101). */
+int sx_feat_fit(const sx_feat_model* model, const double* phi, const double* y, int N, const double* lambda, double* wbar,
+                double* minv, double* stats, int32_t* status, void* stream);
+/* Posterior at z dev [P x D]: same outputs as sx_gp_predict.  Replaces GpCemSSM.predict_* for these kernels. */
+int sx_feat_predict(const sx_feat_model* model, const double* z, int P, double* mean, double* var, double* jac, void* stream);
+/* The CEM particle rollout over such a GP: same arguments and outputs as sx_cem_rollout (no workspace). */
+int sx_cem_rollout_feat(const sx_feat_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
+                        const double* mean, const double* std, const double* noise, double* actions, double* traj,
+                        double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream);
+
 /* Optional kernel timer -- measurement support, not part of the reference's surface (it has no profiler: SURVEY.md 5).
  * While enabled, every launch of the path's kernels is bracketed by a pair of HIP events on the stream the kernel is
  * launched on (at most `max_launches` launches are recorded); sx_profile_collect synchronises those events and returns
@@ -100,7 +134,8 @@ const char* sx_version(void);
 #define SX_PROF_KSTAR_BIG 2      /* kstar_big_kernel   (large-N path) */
 #define SX_PROF_TRMM_BIG 3       /* trmm_reduce_kernel (large-N path) */
 #define SX_PROF_STEP_BIG 4       /* step_big_kernel    (large-N path) */
-#define SX_PROF_KINDS 5
+#define SX_PROF_ROLLOUT_FEAT 5   /* cem_rollout_feat_kernel (degenerate-kernel GPs) */
+#define SX_PROF_KINDS 6
 int sx_profile_enable(int max_launches);
 int sx_profile_stride(int every);   /* time every n-th launch of a kernel class only (default 1): an event pair costs the
                                        launch path a few microseconds, which a 130 us kernel notices */

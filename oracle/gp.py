@@ -94,3 +94,92 @@ class ExactGP:
         """[n_s x N x N] inverse Cholesky factors W_d = L_d^-1 (lower triangular)."""
         eye = np.eye(self.n)
         return np.stack([sla.solve_triangular(self.L[d], eye, lower=True) for d in range(self.n_s)])
+
+
+class FeatureNet:
+    """The feature map of the reference's NNFeatureKernel (ssm_cem/gp_ssm_cem.py:140-185), restated in numpy: Linear,
+    (ReLU, Linear)*, PReLU, then per point  phi = 2 (f - min f) / max f - 1  (the max of the UN-shifted features, as the
+    reference writes it).  `layers` = [(W [out x in], b [out]), ...]; no layers = the identity (the 'linear' kernel)."""
+
+    def __init__(self, layers=(), prelu=0.25, normalise=True):
+        self.layers = [(np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64)) for W, b in layers]
+        self.prelu = float(prelu)
+        self.normalise = bool(normalise) and len(self.layers) > 0
+
+    def __call__(self, z, jacobian=False):
+        """z [P x D] -> phi [P x F] (and d phi / dz [P x F x D])."""
+        z = np.asarray(z, dtype=np.float64)
+        P, D = z.shape
+        a = z
+        J = np.broadcast_to(np.eye(D), (P, D, D)).copy() if jacobian else None
+        for i, (W, b) in enumerate(self.layers):
+            if i > 0:
+                mask = (a > 0).astype(np.float64)
+                a = a * mask
+                if jacobian:
+                    J = J * mask[:, :, None]
+            a = a @ W.T + b
+            if jacobian:
+                J = np.einsum('ok,pkd->pod', W, J)
+        if not self.layers:
+            return (a, J) if jacobian else a
+        slope = np.where(a > 0, 1.0, self.prelu)
+        f = a * slope
+        if jacobian:
+            J = J * slope[:, :, None]
+        if self.normalise:
+            imin, imax = f.argmin(1), f.argmax(1)
+            mn, mx = f[np.arange(P), imin][:, None], f[np.arange(P), imax][:, None]
+            phi = 2.0 * ((f - mn) / mx) - 1.0
+            if jacobian:
+                Jmin, Jmax = J[np.arange(P), imin], J[np.arange(P), imax]          # [P x D]
+                J = 2.0 * ((J - Jmin[:, None, :]) / mx[:, :, None] - ((f - mn) / mx ** 2)[:, :, None] * Jmax[:, None, :])
+        else:
+            phi = f
+        return (phi, J) if jacobian else phi
+
+
+class FeatureGP:
+    """Exact GP with the degenerate kernel k_d(x, x') = c_d phi(x) . phi(x') (reference kernels 'linear' and 'nn':
+    ScaleKernel(LinearKernel / NNFeatureKernel), ssm_cem/gp_ssm_cem.py:45-57), computed in KERNEL space -- N x N Cholesky,
+    exactly like ExactGP above -- so that it checks the device's weight-space form from the other side.  PARITY
+    UNPINNED on values (gpytorch absent).  c [n_s] = outputscale x variance; noise is included in the variance."""
+
+    def __init__(self, X, Y, net: FeatureNet, c, noise):
+        self.X = np.asarray(X, dtype=np.float64)
+        self.Y = np.asarray(Y, dtype=np.float64)
+        self.n, self.D = self.X.shape
+        self.n_s = self.Y.shape[1]
+        self.net = net
+        self.c = np.broadcast_to(np.asarray(c, dtype=np.float64), (self.n_s,)).copy()
+        self.noise = np.broadcast_to(np.asarray(noise, dtype=np.float64), (self.n_s,)).copy()
+        self.Phi = net(self.X)
+        self.L, self.alpha = [], []
+        for d in range(self.n_s):
+            K = self.c[d] * self.Phi @ self.Phi.T + self.noise[d] * np.eye(self.n)
+            L = np.linalg.cholesky(K)
+            self.L.append(L)
+            self.alpha.append(sla.cho_solve((L, True), self.Y[:, d]))
+
+    def predict(self, z, jacobians=True):
+        z = np.asarray(z, dtype=np.float64)
+        phi, J = self.net(z, jacobian=True)
+        P = z.shape[0]
+        mean, var = np.empty((P, self.n_s)), np.empty((P, self.n_s))
+        jac = np.empty((P, self.n_s, self.D)) if jacobians else None
+        for d in range(self.n_s):
+            ks = self.c[d] * phi @ self.Phi.T                                  # [P x N]
+            mean[:, d] = ks @ self.alpha[d]
+            v = sla.solve_triangular(self.L[d], ks.T, lower=True)
+            var[:, d] = self.c[d] * (phi * phi).sum(1) - (v * v).sum(0) + self.noise[d]
+            if jacobians:
+                w = self.c[d] * self.Phi.T @ self.alpha[d]                     # d mean / d phi   [F]
+                jac[:, d, :] = np.einsum('f,pfd->pd', w, J)
+        return mean, var, jac
+
+    def mll(self):
+        """Exact marginal log likelihood per output [n_s]."""
+        out = np.empty(self.n_s)
+        for d in range(self.n_s):
+            out[d] = -0.5 * self.Y[:, d] @ self.alpha[d] - np.log(np.diag(self.L[d])).sum() - 0.5 * self.n * np.log(2 * np.pi)
+        return out

@@ -57,8 +57,15 @@ def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, act
     con = torch.empty((E, P), dtype=torch.float64, device=dev)
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-    model = ssm.device_model
     lib = _lib.lib()
+    if getattr(ssm, 'kernel_family', 'rbf') == 'feature':
+        # degenerate kernels ('linear', 'nn'): the weight-space rollout, one particle per lane (csrc/sx_feat.hpp)
+        _lib.check(lib.sx_cem_rollout_feat(ctypes.byref(ssm.feat_model), ctypes.byref(env), E, P, horizon,
+                                           _lib.ptr(x0.contiguous()), _lib.ptr(q0), _lib.ptr(mean), _lib.ptr(std),
+                                           _lib.ptr(noise), _lib.ptr(actions), _lib.ptr(traj), _lib.ptr(sigma), _lib.ptr(obj),
+                                           _lib.ptr(con), _lib.ptr(status), _lib.stream_ptr(dev)), 'sx_cem_rollout_feat')
+        return dict(actions=actions, obj_cost=obj, con_cost=con, traj=traj, sigma=sigma, status=status)
+    model = ssm.device_model
     ws_bytes = int(lib.sx_cem_rollout_workspace_bytes(ctypes.byref(model), E, P, horizon))
     if ws_bytes < 0:
         raise _lib.SxError('sx_cem_rollout_workspace_bytes: bad arguments')

@@ -19,6 +19,7 @@
 #include "sx_fit_blocked.hpp"
 #include "sx_rollout.hpp"
 #include "sx_rank.hpp"
+#include "sx_feat.hpp"
 
 namespace sx {
 
@@ -571,6 +572,34 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
 
 }  // namespace sx
 
+namespace sx {
+template <int NS, int NU>
+static int launch_feat_predict(const sx_feat_model* m, const double* z, int P, double* mean, double* var, double* jac,
+                               hipStream_t stream) {
+    const FeatConst fc = make_feat_const(m);
+    const size_t lds = kFeatLdsDoubles * sizeof(double);
+    if (int rc = allow_lds(feat_predict_kernel<NS, NU>, lds)) return rc;
+    hipLaunchKernelGGL((feat_predict_kernel<NS, NU>), dim3((P + kFeatWave - 1) / kFeatWave), dim3(kFeatWave), lds, stream, fc, z,
+                       P, mean, var, jac);
+    return check_launch();
+}
+
+template <int NS, int NU>
+static int launch_rollout_feat(const sx_feat_model* m, const sx_env* env, const FeatRolloutPtrs& rp, hipStream_t stream) {
+    const FeatConst fc = make_feat_const(m);
+    ReachConst<NS, NU> rc;
+    if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
+    CostConst<SX_MAX_M, NS, NU> cc;
+    make_cost_const<NS, NU>(env, cc);
+    const size_t lds = kFeatLdsDoubles * sizeof(double);
+    if (int r = allow_lds(cem_rollout_feat_kernel<NS, NU>, lds)) return r;
+    const int64_t total = (int64_t)rp.E * rp.P;
+    launch(SX_PROF_ROLLOUT_FEAT, cem_rollout_feat_kernel<NS, NU>, dim3((unsigned)((total + kFeatWave - 1) / kFeatWave)),
+           dim3(kFeatWave), lds, stream, fc, rc, cc, rp);
+    return check_launch();
+}
+}  // namespace sx
+
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
@@ -916,6 +945,76 @@ int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, in
     sx::RolloutPtrs rp{x0, q0, mean, std, noise, actions, traj, sigma, obj_cost, con_cost, status, E, P, H};
 #define CALL(NS, NU) \
     sx::launch_rollout<NS, NU>(model, env, rp, (double*)workspace, workspace_bytes, (hipStream_t)stream)
+    SX_DISPATCH(model->n_s, model->n_u, CALL);
+#undef CALL
+}
+
+static bool feat_model_ok(const sx_feat_model* m) {
+    if (!m || m->n_s <= 0 || m->n_s > SX_MAX_NS || m->n_u <= 0 || m->n_u > SX_MAX_NU) return false;
+    if (m->n_layers < 0 || m->n_layers > SX_FEAT_MAX_LAYERS || m->n_feat <= 0 || m->n_feat > SX_FEAT_MAX_WIDTH) return false;
+    if (m->width[0] != m->n_s + m->n_u) return false;
+    for (int l = 1; l <= m->n_layers; ++l)
+        if (m->width[l] <= 0 || m->width[l] > SX_FEAT_MAX_WIDTH) return false;
+    if (m->n_layers == 0 ? m->n_feat != m->n_s + m->n_u : (m->n_feat != m->width[m->n_layers] || !m->net)) return false;
+    return true;
+}
+
+int sx_feat_features(const sx_feat_model* model, const double* x, int N, double* phi, void* stream) {
+    if (!feat_model_ok(model) || N < 0) return SX_ERR_ARG;
+    if (N == 0) return SX_OK;
+    if (!x || !phi) return SX_ERR_ARG;
+    const sx::FeatConst fc = sx::make_feat_const(model);
+    const size_t lds = sx::kFeatLdsDoubles * sizeof(double);
+    const dim3 grid((N + sx::kFeatWave - 1) / sx::kFeatWave);
+#define FEAT_D(DD)                                                                                                          \
+    if (fc.d_in == DD) {                                                                                                   \
+        if (int rc = sx::allow_lds(sx::feat_features_kernel<DD>, lds)) return rc;                                          \
+        hipLaunchKernelGGL(sx::feat_features_kernel<DD>, grid, dim3(sx::kFeatWave), lds, (hipStream_t)stream, fc, x, N, phi); \
+        return sx::check_launch();                                                                                         \
+    }
+    FEAT_D(2) FEAT_D(3) FEAT_D(4) FEAT_D(5) FEAT_D(6)
+#undef FEAT_D
+    return SX_ERR_UNSUPPORTED;
+}
+
+int sx_feat_fit(const sx_feat_model* model, const double* phi, const double* y, int N, const double* lambda, double* wbar,
+                double* minv, double* stats, int32_t* status, void* stream) {
+    if (!feat_model_ok(model) || !phi || !y || N <= 0 || !lambda || !wbar || !minv || !stats || !status) return SX_ERR_ARG;
+    sx::FeatFitArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.phi = phi;
+    fa.y = y;
+    for (int d = 0; d < model->n_s; ++d) fa.lambda[d] = lambda[d];
+    fa.wbar = wbar;
+    fa.minv = minv;
+    fa.stats = stats;
+    fa.status = status;
+    fa.n = N;
+    fa.F = model->n_feat;
+    fa.n_s = model->n_s;
+    hipLaunchKernelGGL(sx::feat_fit_kernel, dim3(model->n_s), dim3(1024), 0, (hipStream_t)stream, fa);
+    return sx::check_launch();
+}
+
+int sx_feat_predict(const sx_feat_model* model, const double* z, int P, double* mean, double* var, double* jac, void* stream) {
+    if (!feat_model_ok(model) || P < 0) return SX_ERR_ARG;
+    if (P == 0) return SX_OK;
+    if (!z || !mean || !var || !model->wbar || !model->minv) return SX_ERR_ARG;
+#define CALL(NS, NU) sx::launch_feat_predict<NS, NU>(model, z, P, mean, var, jac, (hipStream_t)stream)
+    SX_DISPATCH(model->n_s, model->n_u, CALL);
+#undef CALL
+}
+
+int sx_cem_rollout_feat(const sx_feat_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
+                        const double* mean, const double* std, const double* noise, double* actions, double* traj,
+                        double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream) {
+    if (!feat_model_ok(model) || !env || !x0 || !actions || !obj_cost || !con_cost || !status) return SX_ERR_ARG;
+    if (!model->wbar || !model->minv || E <= 0 || P <= 0 || H <= 0) return SX_ERR_ARG;
+    if (noise && (!mean || !std)) return SX_ERR_ARG;
+    if (model->n_s != env->n_s || model->n_u != env->n_u) return SX_ERR_ARG;
+    if (env->m <= 0 || env->m > SX_MAX_M) return SX_ERR_UNSUPPORTED;
+    sx::FeatRolloutPtrs rp{x0, q0, mean, std, noise, actions, traj, sigma, obj_cost, con_cost, status, E, P, H};
+#define CALL(NS, NU) sx::launch_rollout_feat<NS, NU>(model, env, rp, (hipStream_t)stream)
     SX_DISPATCH(model->n_s, model->n_u, CALL);
 #undef CALL
 }

@@ -27,13 +27,23 @@ _NOISE_FLOOR = 1e-4
 
 
 class GpCemSSM(CemSSM):
+    kernel_family = 'rbf'   # 'feature' for the degenerate kernels ('linear', 'nn'): feature_gp_ssm_cem.FeatureGpCemSSM
+
+    def __new__(cls, conf=None, *args, **kwargs):
+        # one class name for every kernel, as in the reference (gp_ssm_cem.py:45-57): the 'linear' and 'nn' kernels are
+        # served by the weight-space subclass
+        if cls is GpCemSSM and getattr(conf, 'exact_gp_kernel', 'rbf') in ('linear', 'nn'):
+            from .feature_gp_ssm_cem import FeatureGpCemSSM
+            return super().__new__(FeatureGpCemSSM)
+        return super().__new__(cls)
+
     def __init__(self, conf, state_dimen: int, action_dimen: int, model=None):
         super().__init__(state_dimen, action_dimen)
         if model is not None:
             raise NotImplementedError('injecting a gpytorch model is not supported: the GP is evaluated by libsxamd')
         kernel = getattr(conf, 'exact_gp_kernel', 'rbf')
         if kernel != 'rbf':
-            raise NotImplementedError(f'kernel {kernel!r}: only the ARD-RBF kernel has a HIP implementation')
+            raise ValueError(f'Unknown kernel {kernel}')
         if state_dimen > _lib.SX_MAX_NS or action_dimen > _lib.SX_MAX_NU:
             raise ValueError(f'state/action dimension ({state_dimen}, {action_dimen}) beyond the compiled limits')
         self._device = torch.device(get_device(conf))

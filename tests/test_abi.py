@@ -48,7 +48,10 @@ def test_struct_layouts_match_c(tmp_path):
                    'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sx_gp_model), offsetof(sx_gp_model, inv_ls2),'
                    'offsetof(sx_gp_model, x_train), offsetof(sx_gp_model, stage_tab), sizeof(sx_env),'
                    'offsetof(sx_env, beta), offsetof(sx_env, obj_w_lin));'
-                   'printf("%d %d %d %d %d\\n", SX_MAX_NS, SX_MAX_NU, SX_MAX_M, SX_TILE, SX_WAVES);return 0;}')
+                   'printf("%d %d %d %d %d\\n", SX_MAX_NS, SX_MAX_NU, SX_MAX_M, SX_TILE, SX_WAVES);'
+                   'printf("%zu %zu %zu %zu %zu %d %d\\n", sizeof(sx_feat_model), offsetof(sx_feat_model, width),'
+                   'offsetof(sx_feat_model, prelu), offsetof(sx_feat_model, noise), offsetof(sx_feat_model, minv),'
+                   'SX_FEAT_MAX_WIDTH, SX_FEAT_MAX_LAYERS);return 0;}')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
@@ -56,6 +59,9 @@ def test_struct_layouts_match_c(tmp_path):
     M, E = _lib.SxGpModel, _lib.SxEnv
     want = [ctypes.sizeof(M), M.inv_ls2.offset, M.x_train.offset, M.stage_tab.offset, ctypes.sizeof(E), E.beta.offset,
             E.obj_w_lin.offset, _lib.SX_MAX_NS, _lib.SX_MAX_NU, _lib.SX_MAX_M, _lib.SX_TILE, 8]
+    Fm = _lib.SxFeatModel
+    want += [ctypes.sizeof(Fm), Fm.width.offset, Fm.prelu.offset, Fm.noise.offset, Fm.minv.offset, _lib.SX_FEAT_MAX_WIDTH,
+             _lib.SX_FEAT_MAX_LAYERS]
     assert got == want
 
 

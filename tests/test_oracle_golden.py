@@ -216,3 +216,36 @@ def test_c_oracle_matches_numpy_oracle_on_costs():
         np.testing.assert_allclose(got.obj_cost, ref.obj_cost, rtol=1e-9, atol=1e-12)
         np.testing.assert_array_equal(got.con_cost, ref.con_cost)
         assert got.status == ref.status == 0
+
+
+def test_degenerate_kernel_gp_kernel_space_equals_weight_space():
+    """oracle.gp.FeatureGP ('linear' / 'nn' kernels of gp_ssm_cem.py:45-57,140-185) works in kernel space; the device
+    works in weight space (csrc/sx_feat.hpp).  The two are the same posterior (Woodbury): checked here in numpy, together
+    with the network's analytic Jacobian and the reference's min/max normalisation."""
+    from oracle.gp import FeatureGP, FeatureNet
+    rng = np.random.default_rng(2)
+    net = FeatureNet([(rng.normal(size=(5, 3)), rng.normal(size=5)), (rng.normal(size=(7, 5)), rng.normal(size=7))], prelu=0.25)
+    X = rng.uniform(-1, 1, (50, 3))
+    Y = rng.normal(size=(50, 2)) * 0.1
+    c, noise = np.array([0.4, 0.9]), np.array([2e-3, 5e-3])
+    z = rng.uniform(-1, 1, (9, 3))
+    for n in (net, FeatureNet()):       # nn kernel, linear kernel (identity features)
+        gp = FeatureGP(X, Y, n, c, noise)
+        phi_x, (phi, J) = n(X), n(z, jacobian=True)
+        if n.layers:                    # normalised features: min maps to -1 (2 (f - min) / max - 1), Jacobian == numeric
+            assert np.allclose(phi.min(1), -1.0)
+            for k in range(3):
+                dz = np.zeros(3); dz[k] = 1e-6
+                np.testing.assert_allclose(J[:, :, k], (n(z + dz) - n(z - dz)) / 2e-6, rtol=1e-5, atol=1e-8)
+        mean, var, jac = gp.predict(z)
+        for d in range(2):
+            A = phi_x.T @ phi_x + noise[d] / c[d] * np.eye(phi_x.shape[1])
+            wbar = np.linalg.solve(A, phi_x.T @ Y[:, d])
+            np.testing.assert_allclose(mean[:, d], phi @ wbar, rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(var[:, d], noise[d] * (np.einsum('pf,fg,pg->p', phi, np.linalg.inv(A), phi) + 1.0),
+                                       rtol=1e-7, atol=1e-11)
+            np.testing.assert_allclose(jac[:, d], np.einsum('f,pfd->pd', wbar, J), rtol=1e-7, atol=1e-10)
+            F = phi_x.shape[1]
+            quad = (Y[:, d] @ Y[:, d] - (phi_x.T @ Y[:, d]) @ wbar) / noise[d]
+            logdet = (50 - F) * np.log(noise[d]) + F * np.log(c[d]) + np.linalg.slogdet(A)[1]
+            np.testing.assert_allclose(gp.mll()[d], -0.5 * quad - 0.5 * logdet - 25 * np.log(2 * np.pi), rtol=1e-9)

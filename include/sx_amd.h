@@ -126,8 +126,8 @@ int sx_cem_rollout_feat(const sx_feat_model* model, const sx_env* env, int E, in
                         double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream);
 
 /* Optional kernel timer -- measurement support, not part of the reference's surface (it has no profiler: SURVEY.md 5).
- * While enabled, every launch of the path's kernels is bracketed by a pair of HIP events on the stream the kernel is
- * launched on (at most `max_launches` launches are recorded); sx_profile_collect synchronises those events and returns
+ * While enabled, the launches of the path's kernels (every `sx_profile_stride`-th of each kind) are bracketed by a pair of
+ * hipEventRecord on the stream the kernel is launched on (at most `max_launches` launches are recorded); sx_profile_collect synchronises those events and returns
  * the summed elapsed time and the launch count of one kernel class.  bench.py's `roofline.avg_launch_us` comes from here. */
 #define SX_PROF_ROLLOUT_FUSED 0  /* cem_rollout_kernel            */
 #define SX_PROF_RANK 1           /* cem_rank_kernel               */

@@ -1,6 +1,5 @@
 // libsxamd: launchers + C ABI (include/sx_amd.h) over the kernels in sx_*.hpp.  gfx950 only.
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -316,16 +315,16 @@ static bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop) {
     return true;
 }
 
-// Every kernel of the path is launched through here.  With the timer on, the events ride on the dispatch packet itself
-// (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps, no extra barrier packets on the stream); otherwise
-// this is a plain launch.
+// Every kernel of the path is launched through here.  With the timer on (and this launch sampled), the launch is bracketed
+// by two hipEventRecord on the same stream.  (hipExtLaunchKernelGGL's start / stop events would time the dispatch itself,
+// but a run of config 3 through it ended in a GPU memory access fault that the plain launch does not show; not pursued.)
 template <typename F, typename... Args>
 static void launch(int kind, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
     hipEvent_t start = nullptr, stop = nullptr;
-    if (prof_take(kind, &start, &stop))
-        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, stream, start, stop, 0, args...);
-    else
-        hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+    const bool timed = prof_take(kind, &start, &stop);
+    if (timed) (void)hipEventRecord(start, stream);
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+    if (timed) (void)hipEventRecord(stop, stream);
 }
 
 static int check_launch() {

@@ -390,43 +390,67 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     if (ra.elite_idx)
         for (int i = tid; i < k; i += kRankThreads) ra.elite_idx[(long long)e * k + i] = sel_idx[i];
     if (ra.elite_rows) {
+        // k x (2 + L) gathered elements, 4 per thread and trip with their loads in flight together (the output is a
+        // different buffer: without the restrict qualifiers every load would wait for the store before it)
         const int W = 2 + L;
-        for (int i = tid; i < k * W; i += kRankThreads) {
-            const int r = i / W, c = i - r * W;
-            const int src = sel_idx[r];
-            double v;
-            if (c == 0)
-                v = con[(long long)src * ra.cost_stride];
-            else if (c == 1)
-                v = obj[(long long)src * ra.cost_stride];
-            else
-                v = act[(long long)src * ra.act_stride + (c - 2)];
-            ra.elite_rows[((long long)e * k + r) * W + c] = v;
+        double* __restrict__ rows_out = ra.elite_rows + (long long)e * k * W;
+        const double* __restrict__ con_r = con;
+        const double* __restrict__ obj_r = obj;
+        const double* __restrict__ act_r = act;
+        const int total = k * W;
+        for (int i0 = tid; i0 < total; i0 += 4 * kRankThreads) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kRankThreads;
+                v[u] = 0.0;
+                if (i < total) {
+                    const int r = i / W, c = i - r * W;
+                    const int src = sel_idx[r];
+                    v[u] = (c == 0) ? con_r[(long long)src * ra.cost_stride]
+                                    : (c == 1) ? obj_r[(long long)src * ra.cost_stride] : act_r[(long long)src * ra.act_stride + (c - 2)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kRankThreads;
+                if (i < total) rows_out[i] = v[u];
+            }
         }
     }
     if (ra.best)
         for (int c = tid; c < L; c += kRankThreads) ra.best[(long long)e * L + c] = act[(long long)best_idx * ra.act_stride + c];
     if (ra.best_ok && tid == 0) ra.best_ok[e] = (con[(long long)best_idx * ra.cost_stride] == 0.0) ? 1 : 0;
     if (ra.mean) {
-        // columns in chunks of up to 256; thread t sums rows t / Lc, t / Lc + R, ... of column t % Lc and keeps the first
-        // kKeep values it loaded for the second pass
+        // columns in chunks of up to 256; thread t sums rows t / Lc, t / Lc + R, ... of column t % Lc.  The rows are
+        // gathered kKeep at a time with all loads of a batch in flight together (a row is reached through sel_idx, so a
+        // plain loop would pay one dependent L2 round trip per row: 24 of them at k = 819, L = 30); the first batch stays
+        // in registers for the second pass, the others are read again (L2 hits).
         constexpr int kKeep = 8;
         for (int c0 = 0; c0 < L; c0 += 256) {
             const int Lc = (L - c0) < 256 ? (L - c0) : 256;
             const int R = kRankThreads / Lc;  // row groups
             const int c = tid % Lc, r0 = tid / Lc;
             const bool active = r0 < R;
+            auto gather = [&](int base, double (&v)[kKeep]) {
+#pragma unroll
+                for (int j = 0; j < kKeep; ++j) {
+                    const int r = base + j * R;
+                    v[j] = (r < k) ? act[(long long)sel_idx[r] * ra.act_stride + c0 + c] : 0.0;
+                }
+            };
             double keep[kKeep];
             double s = 0.0;
             if (active) {
-#pragma unroll
-                for (int j = 0; j < kKeep; ++j) {
-                    const int r = r0 + j * R;
-                    keep[j] = (r < k) ? act[(long long)sel_idx[r] * ra.act_stride + c0 + c] : 0.0;
-                }
+                gather(r0, keep);
 #pragma unroll
                 for (int j = 0; j < kKeep; ++j) s += keep[j];
-                for (int r = r0 + kKeep * R; r < k; r += R) s += act[(long long)sel_idx[r] * ra.act_stride + c0 + c];
+                for (int base = r0 + kKeep * R; base < k; base += kKeep * R) {
+                    double v[kKeep];
+                    gather(base, v);
+#pragma unroll
+                    for (int j = 0; j < kKeep; ++j) s += v[j];
+                }
             }
             red[tid] = s;
             __syncthreads();
@@ -440,9 +464,14 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
                     const double dv = keep[j] - mu;
                     if (r0 + j * R < k) ss += dv * dv;
                 }
-                for (int r = r0 + kKeep * R; r < k; r += R) {
-                    const double dv = act[(long long)sel_idx[r] * ra.act_stride + c0 + c] - mu;
-                    ss += dv * dv;
+                for (int base = r0 + kKeep * R; base < k; base += kKeep * R) {
+                    double v[kKeep];
+                    gather(base, v);
+#pragma unroll
+                    for (int j = 0; j < kKeep; ++j) {
+                        const double dv = v[j] - mu;
+                        if (base + j * R < k) ss += dv * dv;
+                    }
                 }
             }
             red[tid] = ss;  // (the column owners finished reading red before the barrier above)

@@ -463,10 +463,15 @@ def test_gp_ssm_shape_contracts_and_edge_cases():
     with pytest.raises(ValueError):
         ssm.update_model(x, y[:, :1])
     assert isinstance(ssm.collect_metrics(), dict)
-    with pytest.raises(NotImplementedError):
-        class LinConf(Conf):
-            exact_gp_kernel = 'linear'
-        GpCemSSM(LinConf(), 2, 1)
+    class LinConf(Conf):
+        exact_gp_kernel = 'linear'
+
+    class OddConf(Conf):
+        exact_gp_kernel = 'matern'
+
+    assert type(GpCemSSM(LinConf(), 2, 1)).__name__ == 'FeatureGpCemSSM'    # tests/test_gpu_feature_gp.py
+    with pytest.raises(ValueError):                                          # the reference's own error (gp_ssm_cem.py:54)
+        GpCemSSM(OddConf(), 2, 1)
 
 
 def test_config3_and_config5_shapes():

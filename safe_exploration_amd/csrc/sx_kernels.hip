@@ -328,6 +328,15 @@ static void launch(int kind, F kernel, dim3 grid, dim3 block, size_t lds, hipStr
 }
 
 static int check_launch() {
+    // SX_DEBUG_SYNC=1: wait for the launch and report an asynchronous failure at the call that caused it (diagnosis only)
+    static const bool debug_sync = std::getenv("SX_DEBUG_SYNC") != nullptr;
+    if (debug_sync) {
+        const hipError_t serr = hipDeviceSynchronize();
+        if (serr != hipSuccess) {
+            std::fprintf(stderr, "libsxamd: kernel failed: %s\n", hipGetErrorString(serr));
+            return SX_ERR_LAUNCH;
+        }
+    }
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         std::fprintf(stderr, "libsxamd: HIP launch error: %s\n", hipGetErrorString(err));

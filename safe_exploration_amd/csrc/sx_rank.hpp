@@ -158,14 +158,23 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     const double* act = ra.actions + (long long)e * P * ra.act_stride;
 
     unsigned long long kh[SLOTS], kl[SLOTS];
+    {
+        // all 2 SLOTS loads of a thread in flight together: the costs were just written by the rollout's workgroups on
+        // other XCDs, so each load is a trip to the fabric, and a load under its own `if (i < P)` waits for the one before
+        // (measured at P = 8192: 20 us of the kernel's 52 went here).  Out-of-range slots read the last candidate instead.
+        double cv[SLOTS], ov[SLOTS];
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int i = s * kRankThreads + tid;
-        kh[s] = ~0ull;
-        kl[s] = ~0ull;
-        if (i < P) {
-            kh[s] = sortable_key(con[(long long)i * ra.cost_stride]);
-            kl[s] = sortable_key(obj[(long long)i * ra.cost_stride]);
+        for (int s = 0; s < SLOTS; ++s) {
+            const int i = s * kRankThreads + tid;
+            const long long ii = (long long)(i < P ? i : P - 1) * ra.cost_stride;
+            cv[s] = con[ii];
+            ov[s] = obj[ii];
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const bool in = s * kRankThreads + tid < P;
+            kh[s] = in ? sortable_key(cv[s]) : ~0ull;
+            kl[s] = in ? sortable_key(ov[s]) : ~0ull;
         }
     }
     if (tid < 256) {
@@ -371,11 +380,18 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         if (s * kRankThreads >= P) break;
         const int i = s * kRankThreads + tid;
         const int entry = s * kRankWaves + wave;
+        // The table offsets are read with v_readlane from lanes that hold no selected candidate themselves: they MUST be
+        // taken here, in wave-uniform control flow.  Inside the `if` below the source lane may be inactive, and the
+        // value an inactive lane holds is undefined (the compiler is free to sink its computation into the branch) --
+        // round 1 did that, and at config 3 (8 slots, many distinct constraint costs) one elite in ~300 rankings landed
+        // in a neighbour's slot, leaving a stale index behind (tests/golden/rank_case_r02.npz).
+        const int off_less = table_offset(tl, ex_l, entry);
+        const int off_tie = table_offset(tt, ex_t, entry);
         int slot = -1;
         if ((my_bl[s] >> lane) & 1ull) {
-            slot = table_offset(tl, ex_l, entry) + __popcll(my_bl[s] & below);
+            slot = off_less + __popcll(my_bl[s] & below);
         } else if ((my_bt[s] >> lane) & 1ull) {
-            const int r = table_offset(tt, ex_t, entry) + __popcll(my_bt[s] & below);
+            const int r = off_tie + __popcll(my_bt[s] & below);
             if (r < need) slot = n_less_total + r;
         }
         if (slot >= 0) sel_idx[slot == best_slot ? 0 : (slot < best_slot ? slot + 1 : slot)] = i;

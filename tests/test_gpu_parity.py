@@ -240,3 +240,22 @@ def test_gp_predict_far_from_the_data_and_nan_queries():
     assert bool(torch.isnan(mean[0]).all()) and bool(torch.isnan(var[0]).all())
     mo, vo, _ = gp.predict(z[1:])
     np.testing.assert_allclose(mean[1:].cpu().numpy(), mo, rtol=1e-9, atol=1e-12)   # its tile neighbour is untouched
+
+
+def test_rank_regression_case_round2(golden_dir):
+    """A ranking that round 1's kernel got wrong (found at BASELINE config 3: 8192 candidates, 12 distinct constraint
+    costs, k = 819): one tied elite landed in a neighbour's slot and a stale index stayed behind -- a v_readlane from an
+    inactive lane.  The saved costs must select exactly the oracle's set, every time."""
+    from safe_exploration_amd.cem_mpc import cem_rank_refit
+    g = np.load(os.path.join(golden_dir, 'rank_case_r02.npz'))
+    con, obj, k = g['con'], g['obj'], int(g['k'])
+    P = len(con)
+    act = np.repeat(np.arange(P, dtype=np.float64)[:, None], 3, axis=1)
+    want = ocem.rank(con, obj, k)
+    for _ in range(5):
+        r = cem_rank_refit(T(con[None]), T(obj[None]), T(act[None]), k, want_rows=True)
+        idx = r['elite_idx'][0].cpu().numpy()
+        assert idx[0] == want[0] and set(idx.tolist()) == set(want.tolist()) and len(set(idx.tolist())) == k
+        np.testing.assert_array_equal(r['elite_rows'][0, :, 2].cpu().numpy(), idx.astype(np.float64))
+        mean, std = ocem.refit(act[want][:, :, None])
+        np.testing.assert_allclose(r['mean'][0].cpu().numpy(), mean[:, 0], rtol=1e-12)

@@ -29,8 +29,10 @@ def main():
     ap.add_argument('--command', default='')
     ap.add_argument('dirs', nargs='+')
     args = ap.parse_args()
-    sums = defaultdict(lambda: defaultdict(float))
-    counts = defaultdict(lambda: defaultdict(int))
+    # a kernel may run in several grid sizes (config 4's warm start predicts ONE point through the large-N kernels, 20 tiny
+    # launches per solve beside the 160 of the rollout): average the launches of the LARGEST grid only -- the ones bench.py
+    # times and prices -- and say how many others were left out
+    by_grid = defaultdict(lambda: defaultdict(lambda: defaultdict(list)))
     full_names = {}
     for d in args.dirs:
         for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
@@ -39,9 +41,19 @@ def main():
                     name = row['Kernel_Name']
                     for key in KERNELS:
                         if key in name:
-                            sums[key][row['Counter_Name']] += float(row['Counter_Value'])
-                            counts[key][row['Counter_Name']] += 1
+                            by_grid[key][int(row['Grid_Size'])][row['Counter_Name']].append(float(row['Counter_Value']))
                             full_names[key] = name
+    sums = defaultdict(lambda: defaultdict(float))
+    counts = defaultdict(lambda: defaultdict(int))
+    other_grids = {}
+    for key, grids in by_grid.items():
+        top = max(grids)
+        for cname, vals in grids[top].items():
+            sums[key][cname] = sum(vals)
+            counts[key][cname] = len(vals)
+        left = {str(g): max(len(v) for v in c.values()) for g, c in grids.items() if g != top}
+        if left:
+            other_grids[key] = {'grid_size_averaged': top, 'launches_left_out_by_grid_size': left}
     per_launch = {k: {c: sums[k][c] / counts[k][c] for c in sorted(sums[k])} for k in sums}
     launches = {k: max(counts[k].values()) for k in counts}
     out = {
@@ -51,6 +63,7 @@ def main():
         'workload': args.workload,
         'kernel_names': full_names,
         'launches_counted': launches,
+        'other_grid_sizes': other_grids,
         'per_launch_averages': per_launch,
         'notes': [
             'FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide '

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     __shared__ unsigned long long red_h[kRankWaves], red_l[kRankWaves];
     __shared__ int red_i[kRankWaves];
     __shared__ unsigned long long walk_min[8];
+    __shared__ unsigned long long hdiff_cell;   // bits in which the constraint words of the candidates differ at all
     __shared__ int walk_cnt[8];
     __shared__ int cnt_less[kEntries], cnt_tie[kEntries];
     __shared__ unsigned long long ball_less[kEntries], ball_tie[kEntries];
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
         walk_min[tid] = ~0ull;
         walk_cnt[tid] = 0;
     }
+    if (tid == 0) hdiff_cell = 0ull;
 
 #ifdef SX_STAMPS
     const unsigned long long ts0 = stamp();
@@ -224,32 +226,42 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     int first_pass = 0;
     {
         // The constraint word takes few distinct values (0 for every feasible particle, then 3 a + 10 b), so its
-        // k-th smallest value is found by walking up the distinct values, at most 8 of them (beyond that the general
-        // passes below take over).  The smallest one is the best candidate's; its multiplicity comes from ballots.
+        // k-th smallest value is found by walking up the distinct values, at most kWalk of them (beyond that the general
+        // passes below take over: a long horizon has dozens of values).  The smallest one is the best candidate's; its
+        // multiplicity comes from ballots.  The first iteration's barrier also publishes in which BYTES the constraint
+        // words differ at all: small integers stored as doubles share their low mantissa bytes, and a radix pass over
+        // a byte in which no two candidates differ would only confirm that (6 of 8 passes at config 3).
+        constexpr int kWalk = 5;
         unsigned long long cur = bh;
         int acc = 0;  // candidates below `cur`
-        for (int it = 0; it < 8; ++it) {
-            if (it > 0) {
-                // next distinct value above the previous one
-                unsigned long long mn = ~0ull;
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s)
-                    if ((s * kRankThreads + tid < P) && kh[s] > cur && kh[s] < mn) mn = kh[s];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const unsigned long long om = __shfl_xor(mn, off);
-                    if (om < mn) mn = om;
-                }
-                if (lane == 0 && mn != ~0ull) atomicMin(&walk_min[it], mn);
-                __syncthreads();
-                cur = walk_min[it];
-                if (cur == ~0ull) break;  // no further value (cannot happen while acc < k <= P, kept for safety)
-            }
-            int cnt = 0;
+        {
+            unsigned long long dif = 0ull;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s)
-                cnt += __popcll(__ballot((s * kRankThreads + tid < P) && kh[s] == cur));
-            if (lane == 0) atomicAdd(&walk_cnt[it], cnt);
+                if (s * kRankThreads + tid < P) dif |= kh[s] ^ bh;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dif |= __shfl_xor(dif, off);
+            if (lane == 0 && dif) atomicOr(&hdiff_cell, dif);
+        }
+        for (int it = 0; it < kWalk; ++it) {
+            // ONE barrier per distinct value: the multiplicity of `cur` and the next value above it in the same round
+            int cnt = 0;
+            unsigned long long mn = ~0ull;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const bool in = s * kRankThreads + tid < P;
+                cnt += __popcll(__ballot(in && kh[s] == cur));
+                if (in && kh[s] > cur && kh[s] < mn) mn = kh[s];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long om = __shfl_xor(mn, off);
+                if (om < mn) mn = om;
+            }
+            if (lane == 0) {
+                atomicAdd(&walk_cnt[it], cnt);
+                if (mn != ~0ull) atomicMin(&walk_min[it], mn);
+            }
             __syncthreads();
             cnt = walk_cnt[it];
             if (acc + cnt >= k) {   // the k-th key has this constraint word
@@ -260,6 +272,8 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
                 break;
             }
             acc += cnt;
+            cur = walk_min[it];
+            if (cur == ~0ull) break;  // no further value (cannot happen while acc < k <= P, kept for safety)
         }
     }
 #ifdef SX_STAMPS
@@ -267,21 +281,31 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
     int npass = 0;
     unsigned long long pass_t[3] = {0, 0, 0};
 #endif
+    const unsigned long long hdiff = hdiff_cell;   // (published by the walk's first barrier)
+    int hp = 0;                                    // executed passes: the histogram buffers rotate with it
     for (int pass = first_pass; pass < 16 && !done; ++pass) {
+        const int shift = 56 - 8 * (pass & 7);
+        const bool in_hi = pass < 8;
+        if (in_hi && ((hdiff >> shift) & 255ull) == 0ull) {
+            // every candidate has the best candidate's byte here: it joins the prefix without a pass
+            ph |= bh & (255ull << shift);
+            mh |= 255ull << shift;
+            continue;
+        }
 #ifdef SX_STAMPS
         ++npass;
 #endif
-        const int shift = 56 - 8 * (pass & 7);
-        const bool in_hi = pass < 8;
-        unsigned int* h = hist[pass % 3];
+        unsigned int* h = hist[hp % 3];
         // the buffer of the next pass was last read two passes ago: clear it now, behind this pass's barrier
-        if (tid < 256) hist[(pass + 1) % 3][tid] = 0;
+        if (tid < 256) hist[(hp + 1) % 3][tid] = 0;
+        ++hp;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int i = s * kRankThreads + tid;
             const bool match = (i < P) && ((kh[s] & mh) == ph) && ((kl[s] & ml) == pl);
             const unsigned int digit = match ? (unsigned int)(((in_hi ? kh[s] : kl[s]) >> shift) & 255ull) : 0xffffffffu;
-            // (a ballot-per-distinct-digit aggregation was measured twice: slower than the plain atomics it saves)
+            // (a ballot-per-distinct-digit aggregation was measured three times, round 2 for the constraint word alone with
+            // its handful of digits per wave: slower than the plain atomics it saves)
             const unsigned int first = __builtin_amdgcn_readfirstlane(digit);
             if (__all(digit == first)) {
                 if (first != 0xffffffffu && lane == 0) atomicAdd(&h[first], 64u);

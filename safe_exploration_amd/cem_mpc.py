@@ -177,6 +177,36 @@ RANK_MAX_CANDIDATES = 16384
 RANK_MAX_ELITES = 2048
 
 
+def rank_chunks(num_candidates: int) -> int:
+    """Chunks a ranking of `num_candidates` is split into (1 = the kernel takes them at once): the smallest count that
+    divides the candidates evenly into chunks of at most RANK_MAX_CANDIDATES."""
+    c = -(-num_candidates // RANK_MAX_CANDIDATES)
+    while num_candidates % c:
+        c += 1
+    return c
+
+
+def cem_rank_refit_any(con: Tensor, obj: Tensor, actions: Tensor, k: int, **kw):
+    """`cem_rank_refit` for any candidate count.  Beyond the kernel's 16 384 candidates per problem (BASELINE config 3's
+    65 536 particles on ONE GPU) the ranking runs in two levels, exactly like the multi-GPU exchange without the collective:
+    the C chunks of a problem hand in their top-k rows (one launch, E x C workgroups side by side), a second launch ranks
+    the C k candidates.  `elite_idx` then numbers candidate rows, not particles (as after the exchange); equal
+    (constraint, objective) pairs across chunks are ordered by chunk, not by particle index."""
+    E, P = con.shape
+    C = rank_chunks(P)
+    if C == 1:
+        return cem_rank_refit(con, obj, actions, k, **kw)
+    Pc, L = P // C, actions[0, 0].numel()
+    if k > Pc or C * k > RANK_MAX_CANDIDATES:
+        raise ValueError(f'{P} candidates rank in {C} chunks of {Pc}: k={k} must not exceed the chunk size, nor '
+                         f'{C} k the kernel\'s {RANK_MAX_CANDIDATES}')
+    local = cem_rank_refit(con.reshape(E * C, Pc), obj.reshape(E * C, Pc), actions.reshape(E * C, Pc, L), k,
+                           want_rows=True, want_refit=False)
+    flat = local['elite_rows'].reshape(-1)                       # [E x C k x (2 + L)] candidate rows
+    return cem_rank_refit(flat, flat[1:], flat[2:], k, cost_stride=2 + L, act_stride=2 + L, row_len=L,
+                          num_candidates=C * k, num_problems=E, **kw)
+
+
 def fold_status(words) -> int:
     """Bitwise OR of the per-rank status words `solve` returns (host side: a handful of ints)."""
     out = 0
@@ -223,12 +253,15 @@ class FusedCemMpc:
                              f'({num_rollouts // self._world} of {num_rollouts} particles over {self._world} GPUs)')
         self._num_elites = num_elites
         self._local_elites = num_elites     # the same k on every rank
-        for what, count in (('particles per GPU', self._local_rollouts + (1 if num_rollouts % self._world else 0)),
-                            ('candidates after the exchange', self._world * num_elites if self._world > 1 else 0)):
-            if count > RANK_MAX_CANDIDATES:
-                raise ValueError(f'{count} {what} exceed the ranking kernel\'s limit of {RANK_MAX_CANDIDATES}')
         if num_elites > RANK_MAX_ELITES:
             raise ValueError(f'num_elites={num_elites} exceeds the ranking kernel\'s limit of {RANK_MAX_ELITES}')
+        if self._world > 1 and self._world * num_elites > RANK_MAX_CANDIDATES:
+            raise ValueError(f'{self._world * num_elites} candidates after the exchange exceed the ranking kernel\'s limit '
+                             f'of {RANK_MAX_CANDIDATES}')
+        chunks = rank_chunks(self._local_rollouts)     # > 1: two-level ranking on this GPU (cem_rank_refit_any)
+        if chunks > 1 and (num_elites > self._local_rollouts // chunks or chunks * num_elites > RANK_MAX_CANDIDATES):
+            raise ValueError(f'{self._local_rollouts} particles per GPU rank in {chunks} chunks: num_elites={num_elites} is '
+                             f'too large for it (limit {min(self._local_rollouts // chunks, RANK_MAX_CANDIDATES // chunks)})')
         self._device = torch.device(device if device is not None else 'cuda:0')
         self._init_std = self._init_std.to(self._device)
         self._gen = torch.Generator(device=self._device)
@@ -347,17 +380,17 @@ class FusedCemMpc:
                 ev[1].record(torch.cuda.current_stream(dev))
                 self.rollout_events.append(ev)
             if self._world == 1:
-                out = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites)
+                out = cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites)
             else:
                 k = self._local_elites
                 if xch is None:
                     xch = distributed.EliteExchange(self._num_iterations, E, k, L, self._group, dev)
                 if E == 1:
                     # the local elite rows go straight into this rank's slot: no copy between the kernel and the collective
-                    cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_refit=False,
-                                   rows_out=xch.local_slot(it))
+                    cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], k, want_refit=False,
+                                       rows_out=xch.local_slot(it))
                 else:
-                    local = cem_rank_refit(r['con_cost'], r['obj_cost'], r['actions'], k, want_rows=True, want_refit=False)
+                    local = cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], k, want_rows=True, want_refit=False)
                     xch.local_slot(it).copy_(local['elite_rows'])
                 last = it == self._num_iterations - 1
                 if self.exchange_events is not None:

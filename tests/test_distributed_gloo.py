@@ -90,8 +90,10 @@ def test_constructor_refuses_what_the_exchange_cannot_serve():
     try:
         with pytest.raises(ValueError, match='smallest per-GPU share'):
             cem_mpc.FusedCemMpc(_Ssm(), None, 5, 5, 3, 2, device='cpu', process_group=_Group())
-        with pytest.raises(ValueError, match='limit'):
-            cem_mpc.FusedCemMpc(_Ssm(), None, 5, 40000, 10, 2, device='cpu')
+        cem_mpc.FusedCemMpc(_Ssm(), None, 5, 40000, 10, 2, device='cpu')          # ranks in 4 chunks of 10 000
+        assert cem_mpc.rank_chunks(16384) == 1 and cem_mpc.rank_chunks(65536) == 4 and cem_mpc.rank_chunks(40000) == 4
+        with pytest.raises(ValueError, match='too large'):
+            cem_mpc.FusedCemMpc(_Ssm(), None, 5, 262144, 2048, 2, device='cpu')      # 16 chunks x 2048 rows > 16 384
         with pytest.raises(ValueError, match='limit'):
             cem_mpc.FusedCemMpc(_Ssm(), None, 5, 16384, 4096, 2, device='cpu')
         with pytest.raises(ValueError, match='warm_start'):

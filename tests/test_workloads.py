@@ -256,3 +256,34 @@ def test_bench_launches_its_own_ranks():
     assert line['n_gpus'] == 2 and line['device_status'] == 0 and line['exchange_us'] > 0
     assert line['config']['baseline_config'] == 1 and line['config']['backend'] == 'gloo'
     assert 0 < line['roofline']['frac'] <= 1.0 and line['value'] > 0
+
+
+@pytest.mark.gpu
+def test_config3_whole_problem_on_one_gpu():
+    """All 65 536 particles of config 3 on ONE GPU (round 1: refused beyond 16 384 per GPU): the ranking runs in two levels
+    (4 chunks hand in their top-k rows, a second launch ranks the 4 k candidates), like the multi-GPU exchange without the
+    collective.  The two-level selection equals the oracle's ranking of all candidates; the solve finishes with status 0."""
+    import torch
+    from safe_exploration_amd.cem_mpc import FusedCemMpc, cem_rank_refit_any, rank_chunks
+    rng = np.random.default_rng(8)
+    P, k, L = 40000, 500, 7
+    assert rank_chunks(P) == 4
+    con = rng.choice([0., 0., 3., 10., 13., 20.], size=(2, P))
+    obj = rng.normal(size=(2, P))
+    act = rng.normal(size=(2, P, L))
+    r = cem_rank_refit_any(T(con), T(obj), T(act), k, want_rows=True)
+    for e in range(2):
+        want = ocem.rank(con[e], obj[e], k)
+        rows = r['elite_rows'][e].cpu().numpy()
+        np.testing.assert_array_equal(rows[0, 2:], act[e, want[0]])                       # the best first
+        got = {tuple(v) for v in rows[:, 2:]}
+        assert got == {tuple(v) for v in act[e, want]}
+        mean, std = ocem.refit(act[e, want][:, :, None])
+        np.testing.assert_allclose(r['mean'][e].cpu().numpy(), mean[:, 0], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(r['std'][e].cpu().numpy(), std[:, 0], rtol=1e-11, atol=1e-14)
+        assert int(r['best_ok'][e]) == int(con[e, want[0]] == 0)
+    w = problems.baseline_workload(3)
+    ssm, env = problems.build(w.spec, DEV)
+    mpc = FusedCemMpc(ssm, env, w.horizon, 65536, 2048, 2, device=DEV, seed=5, init_std=w.init_std)
+    best, ok, _, status = mpc.solve(T(w.x0[:1]))
+    assert int(status.item()) == 0 and int(ok[0]) == 1 and bool(torch.isfinite(best).all())

@@ -184,8 +184,19 @@ __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <=
     // XCD-aware decode (see above); any grid whose size is not a multiple of 8 keeps the plain order
     int id = blockIdx.x;
     const int total = gridDim.x;
-    int rt, pg, d;
-    if (xcd_aware & 8) {
+    int rt, pg, d, rt_second = -1;
+    if (xcd_aware & 16) {
+        // PAIRED tiles (small grids): this workgroup does row tile row_tiles - 1 - j and then row tile j -- every workgroup
+        // the same work, so a launch of one or two rounds has no tail however the dispatcher places it (longest-first
+        // cannot pack 512 workgroups of 8 : 1 unequal work onto 768 slots: the N ~ 1000 step of tools/n_sweep.sh)
+        const int half = (row_tiles + 1) >> 1;
+        pg = id % pgroups;
+        d = (id / pgroups) % NS;
+        const int j = id / (pgroups * NS);
+        rt = row_tiles - 1 - j;
+        if (j != rt) rt_second = j;
+        (void)half;
+    } else if (xcd_aware & 8) {
         // longest first: row tile rt does (rt + 1) / row_tiles of the longest tile's work, so the tiles are dealt out in
         // descending rt (particle group fastest: the workgroups that run together share their W row tile through L2)
         pg = id % pgroups;
@@ -198,23 +209,30 @@ __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <=
         d = id / (row_tiles * pgroups);
     }
     const int pg_src = (xcd_aware & 2) ? 0 : pg;     // (diagnostic, timing only: every workgroup reads particle group 0's Kstar)
+    const int nrb = gc.n_pad >> 4;
+    const int64_t wpo = w_pairs_per_output(nrb);
+    const int64_t tstride = (int64_t)(gc.n_pad >> 3) * 64;           // 16-byte elements per particle tile
+    // buffer descriptors: W of output d (reads beyond it return 0), the 8 Kstar particle tiles of this workgroup
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(gc.a_pack) + (int64_t)d * wpo * 128, 0, (int)(wpo * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
+        ws.ks + (((int64_t)d * (p128 / 16) + (int64_t)pg_src * kBigRb) * tstride) * 2, 0, (int)(kBigRb * tstride * 16), 0x00020000);
+    const bool is_k = wave >= 2;
+    const int lane16 = lane * 16;
+  for (int rep = 0; rep < 2; ++rep) {
+    if (rep == 1) {
+        if (rt_second < 0) break;
+        rt = rt_second;
+        __syncthreads();     // everyone is done with the first tile's LDS buffers before they are refilled
+    }
     const int rt_src = (xcd_aware & 4) ? 0 : rt;     // (diagnostic, timing only: every workgroup reads row tile 0's W)
     const int nrb = gc.n_pad >> 4;
     const int rb0 = rt * kBigRb;
     const int rb_end = (rb0 + kBigRb < nrb) ? rb0 + kBigRb : nrb;   // exclusive
     const int npairs = 2 * rb_end;                                   // K extent of the tile's longest row-block
     const int nchunks = (npairs + PPC - 1) / PPC;
-    const int64_t wpo = w_pairs_per_output(nrb);
-    const int64_t tstride = (int64_t)(gc.n_pad >> 3) * 64;           // 16-byte elements per particle tile
-
-    // buffer descriptors: W of output d (reads beyond it return 0), the 8 Kstar particle tiles of this workgroup
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double*>(gc.a_pack) + (int64_t)d * wpo * 128, 0, (int)(wpo * 1024), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
-        ws.ks + (((int64_t)d * (p128 / 16) + (int64_t)pg_src * kBigRb) * tstride) * 2, 0, (int)(kBigRb * tstride * 16), 0x00020000);
     // this wave's DMA pieces of a chunk: waves 0, 1 fetch the W fragments, waves 2, 3 the Kstar fragments;
     // piece i = fragment f = kPieces (wave & 1) + i -> (block f / PPC, pair f % PPC)
-    const bool is_k = wave >= 2;
     int piece_off[kPieces];     // byte offset of the fragment at q0 = 0 (SGPRs)
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
@@ -222,7 +240,6 @@ __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <=
         const int rb = rt_src * kBigRb + blk;
         piece_off[i] = is_k ? (int)((blk * tstride + pr * 64) * 16) : (rb * (rb + 1) + pr) * 1024;
     }
-    const int lane16 = lane * 16;
     auto issue_chunk = [&](int chunk, int buf) {
 #pragma unroll
         for (int i = 0; i < kPieces; ++i) {
@@ -314,6 +331,7 @@ __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <=
         s += __shfl_xor(s, 32);
         if (lane < 16) ws.part[((int64_t)d * row_tiles * 2 + rt * 2 + wr) * p128 + p] = s;
     }
+  }   // rep
 }
 
 // ---- 3. per-particle step ------------------------------------------------------------------------------------------

@@ -432,26 +432,57 @@ static int launch_polytope(const sx_env* env, int P, const double* p, const doub
 }
 
 // trmm_reduce_kernel variants, selectable for A/B measurements (tools/cfg4_probe.py):
-//   SX_TRMM_ORDER   = tile order bits: 8 longest-first (default), 1 XCD-contiguous with the row tile fastest, 0 plain;
+//   SX_TRMM_ORDER   = tile order bits: 16 paired tiles (default for small grids), 8 longest-first (default otherwise),
+//                     1 XCD-contiguous with the row tile fastest, 0 plain;
 //                     + 2 / + 4: timing-only diagnostics (every workgroup reads the same Kstar / W tile: no fabric traffic)
 //   SX_TRMM_VARIANT = <pairs per chunk><LDS buffers>: 13 (default), 12, 22, 23
 // Measured at config 4 (N = 2000, 16 384 particles), per launch: plain order 7.2 ms, XCD-contiguous 4.73 ms, longest-first
 // 3.92 ms -- whatever the variant, and the same with the fabric traffic removed (order + 6): the kernel was never
 // memory-bound, its tiles differ 16-fold in work and the tail of the launch was what it lost.
-static const int g_trmm_xcd_aware = std::getenv("SX_TRMM_ORDER") ? std::atoi(std::getenv("SX_TRMM_ORDER")) : 8;
+static const int g_trmm_order = std::getenv("SX_TRMM_ORDER") ? std::atoi(std::getenv("SX_TRMM_ORDER")) : -1;
 static const int g_trmm_variant = std::getenv("SX_TRMM_VARIANT") ? std::atoi(std::getenv("SX_TRMM_VARIANT")) : 13;
 
 template <int NS, int D, int PPC, int NBUF>
 static void launch_trmm_v(int kind, const GpConst<NS, D>& gc, const BigWs& ws, int64_t p128, int row_tiles, hipStream_t stream) {
     constexpr int lds = big_lds_bytes<PPC, NBUF>();
     (void)allow_lds(trmm_reduce_kernel<NS, D, PPC, NBUF>, lds);
-    const dim3 grid((unsigned)((p128 / kBigTile) * row_tiles * NS));
+    const int64_t tiles = (p128 / kBigTile) * row_tiles * NS;
+    // Tile order.  A large grid runs longest tile first.  A grid of a few rounds is all quantisation: it runs PAIRED tiles
+    // (row tile rt and row_tiles - 1 - rt in one workgroup: equal work) when that deals the work out more evenly than
+    // longest-first does -- judged by dealing the workgroups round-robin onto the 256 CUs and comparing the fullest CU.
+    // SX_TRMM_ORDER overrides.
+    int order = g_trmm_order;
+    if (order < 0) {
+        order = 8;
+        if (tiles <= 3 * 768 && row_tiles > 1) {
+            const int nrb = gc.n_pad >> 4, groups = (int)(p128 / kBigTile) * NS;
+            std::vector<double> work(row_tiles);
+            for (int rt = 0; rt < row_tiles; ++rt) {
+                const int rb0 = rt * kBigRb, rb_end = rb0 + kBigRb < nrb ? rb0 + kBigRb : nrb;
+                double w = 0.0;
+                for (int rb = rb0; rb < rb0 + kBigRb; ++rb) w += 2 * (rb + 1) < 2 * rb_end ? 2 * (rb + 1) : 2 * rb_end;
+                work[rt] = w;
+            }
+            auto fullest = [&](const std::vector<double>& per_wg) {     // per_wg: work of the workgroups in dispatch order
+                double cu[256] = {0.0};
+                for (size_t i = 0; i < per_wg.size(); ++i) cu[i & 255] += per_wg[i];
+                double m = 0.0;
+                for (double v : cu) m = v > m ? v : m;
+                return m;
+            };
+            std::vector<double> plain, paired;
+            for (int rt = row_tiles - 1; rt >= 0; --rt) plain.insert(plain.end(), groups, work[rt]);
+            for (int j = 0; j < (row_tiles + 1) / 2; ++j)
+                paired.insert(paired.end(), groups, work[row_tiles - 1 - j] + (j != row_tiles - 1 - j ? work[j] : 0.0));
+            if (fullest(paired) < fullest(plain)) order = 16;
+        }
+    }
+    const dim3 grid((unsigned)((order & 16) ? (p128 / kBigTile) * ((row_tiles + 1) / 2) * NS : tiles));
     if (kind >= 0)
-        launch(kind, trmm_reduce_kernel<NS, D, PPC, NBUF>, grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles,
-               g_trmm_xcd_aware);
+        launch(kind, trmm_reduce_kernel<NS, D, PPC, NBUF>, grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles, order);
     else
         hipLaunchKernelGGL((trmm_reduce_kernel<NS, D, PPC, NBUF>), grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles,
-                           g_trmm_xcd_aware);
+                           order);
 }
 
 template <int NS, int D>

@@ -24,8 +24,8 @@ for i in range(3):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     k = _lib.profile_collect(); lib.sx_profile_disable()
     st = int(r['status'].item())
-    if st != 0 and not (int(os.environ.get("SX_TRMM_ORDER", "8")) & 6):
+    if st != 0 and not (int(os.environ.get("SX_TRMM_ORDER", "0")) & 6):
         raise SystemExit(f'device status {st}: no throughput reported')
     feas = float((r['con_cost'] == 0).double().mean())
-    print(f'variant {os.environ.get("SX_TRMM_VARIANT", "13")} order {os.environ.get("SX_TRMM_ORDER", "8")} rollout P={P} H={H} N={N}: {dt*1e3:.1f} ms  {P*H/dt:.3e} particle-steps/s  status {st} feasible {feas:.3f}  '
+    print(f'variant {os.environ.get("SX_TRMM_VARIANT", "13")} order {os.environ.get("SX_TRMM_ORDER", "0")} rollout P={P} H={H} N={N}: {dt*1e3:.1f} ms  {P*H/dt:.3e} particle-steps/s  status {st} feasible {feas:.3f}  '
           + '  '.join(f'{n} {ms/c*1e3:.0f}us' for n, (ms, c) in k.items()), flush=True)

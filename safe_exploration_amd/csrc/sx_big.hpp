@@ -90,10 +90,13 @@ __global__ void init_big_kernel(BigInit bi, BigWs ws, int64_t total, int64_t p12
 }
 
 // ---- 1. Kstar -> HBM in fragment order ---------------------------------------------------------------------------
-// grid (P128 / 16, k chunks of 256); thread = (query point c = tid & 15, k = chunk * 256 + (tid >> 4) + 16 i)
+// grid (P128 / 16, chunks of 32 fragment pairs = 256 k); thread = (query point c = tid & 15, kk = (tid >> 4) & 3, pair
+// q = 32 chunk + 4 i + (tid >> 6)).  A thread computes BOTH slots of one 16-byte fragment element (rows 8 q + kk and
+// 8 q + kk + 4), so a wave stores 64 consecutive elements -- 1 KB, whole lines -- per output and trip (round 1 wrote the two
+// slots of an element from different trips: half-filled 16-byte elements, 4.0 TB/s; the kernel is HBM-write bound).
 template <int NS, int D>
 __global__ __launch_bounds__(256) void kstar_big_kernel(GpConst<NS, D> gc, BigWs ws) {
-    const int tile = blockIdx.x, c = threadIdx.x & 15;
+    const int tile = blockIdx.x, c = threadIdx.x & 15, kk = (threadIdx.x >> 4) & 3, qw = threadIdx.x >> 6;
     // the table-driven exp of the fused path (sx_gp.hpp): 2^(j/256) in LDS, behind it the NaN table of a NaN query
     __shared__ double etab_s[2 * kExpTab];
     etab_s[threadIdx.x] = kExp2Tab[threadIdx.x];
@@ -108,21 +111,24 @@ __global__ __launch_bounds__(256) void kstar_big_kernel(GpConst<NS, D> gc, BigWs
     }
     __syncthreads();
     const lds_f64* etab = (const lds_f64*)etab_s + (znan ? kExpTab : 0);
-    const int64_t tstride = (int64_t)(gc.n_pad >> 3) * 128;
+    const int npairs = gc.n_pad >> 3;
+    const int64_t tstride = (int64_t)npairs * 64;                 // 16-byte elements per particle tile
     const int64_t dstride = (int64_t)gridDim.x * tstride;
-    const int kbase = blockIdx.y * 256;
-    for (int i = 0; i < 16; i += 2) {
+    v2d* out = reinterpret_cast<v2d*>(ws.ks) + (int64_t)tile * tstride + (kk << 4) + c;
+    for (int i = 0; i < 8; ++i) {
+        const int q = blockIdx.y * 32 + 4 * i + qw;
+        if (q >= npairs) break;                                   // (wave-uniform)
         double arg[2 * NS], val[2 * NS];
         int ks[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int k = kbase + (threadIdx.x >> 4) + 16 * (i + h);
+            const int k = 8 * q + kk + 4 * h;
             ks[h] = k;
-            const int kk = k < gc.n_train ? k : 0;
+            const int kr = k < gc.n_train ? k : 0;
             double sq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const double df = z[j] - gc.x_train[(int64_t)kk * D + j];
+                const double df = z[j] - gc.x_train[(int64_t)kr * D + j];
                 sq[j] = df * df;
             }
 #pragma unroll
@@ -135,14 +141,8 @@ __global__ __launch_bounds__(256) void kstar_big_kernel(GpConst<NS, D> gc, BigWs
         }
         exp_tab_f64_n<2 * NS>(arg, val, etab);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (ks[h] < gc.n_pad) {
-                const int fi = frag_index(c, ks[h]);
-#pragma unroll
-                for (int d = 0; d < NS; ++d)
-                    ws.ks[d * dstride + tile * tstride + fi] = (ks[h] < gc.n_train) ? val[h * NS + d] : 0.0;
-            }
-        }
+        for (int d = 0; d < NS; ++d)
+            out[d * dstride + (int64_t)q * 64] = v2d{ks[0] < gc.n_train ? val[d] : 0.0, ks[1] < gc.n_train ? val[NS + d] : 0.0};
     }
 }
 

@@ -366,8 +366,17 @@ __global__ void step_big_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, 
     for (int c = 0; c < NU; ++c) u[c] = z[NS + c];
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
+        // (partial sums in a FIXED order; the loads of 8 of them in flight together: each is an L2 / fabric round trip)
         double q = 0.0;
-        for (int r = 0; r < bs.row_parts; ++r) q += ws.part[((int64_t)d * bs.row_parts + r) * p128 + g];
+        int r = 0;
+        for (; r + 8 <= bs.row_parts; r += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws.part[((int64_t)d * bs.row_parts + r + u) * p128 + g];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q += v[u];
+        }
+        for (; r < bs.row_parts; ++r) q += ws.part[((int64_t)d * bs.row_parts + r) * p128 + g];
         var[d] = (gc.outputscale[d] - q) + gc.noise[d];
         const double m = ws.mj[((int64_t)d * (D + 1)) * p128 + g];
         mean[d] = m;

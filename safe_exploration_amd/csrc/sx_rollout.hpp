@@ -65,6 +65,12 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     const int e = blockIdx.x / tiles_per_problem;
     const int c0 = (blockIdx.x - e * tiles_per_problem) * SX_TILE;  // first particle of the tile within problem e
 
+    // The head of this wave's MFMA stream (stage count, first descriptors, first W fragments: two dependent round trips to
+    // L2) is requested first of all, so that it travels while X, the exp table and the actions are loaded: the launch's
+    // fixed cost is ~8 us of its 127 (tools: bench.py --horizon 1 .. 15), all of it dependent loads like these.
+    // (in the output-by-output mode every phase fetches the head of its own stream)
+    const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane, gc.stage_cap);
+    const int4* __restrict__ const tab_one = stage_tab + (size_t)nw * (1 + gc.stage_cap);
     gp_load_xs(gc, lds);
     // sample (or load) this tile's action sequences: a = mean + std * eps
     for (int i = tid; i < SX_TILE * H * NU; i += blockDim.x) {
@@ -201,9 +207,6 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
     const unsigned long long ct0 = stamp();
 #endif
-    // (in the output-by-output mode every phase fetches the head of its own stream)
-    const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane, gc.stage_cap);
-    const int4* __restrict__ const tab_one = stage_tab + (size_t)nw * (1 + gc.stage_cap);
     // Kstar shares (pairs of fragments).  Step 0: all waves alike.  From step 1 on wave 0 runs finish(); waves w and w + 4
     // share a SIMD, so wave 4 competes with finish() for its pipe and gets half a share (weight 1 against 2).
     int q0_begin, q0_end, q_begin = 0, q_end = 0;

@@ -125,6 +125,31 @@ int sx_cem_rollout_feat(const sx_feat_model* model, const sx_env* env, int E, in
                         const double* mean, const double* std, const double* noise, double* actions, double* traj,
                         double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream);
 
+/* ---- MC-dropout state-space models: ssm_cem/dropout_ssm_cem.py, gal_concrete_dropout.py ----
+ * An ensemble of S thinned ReLU networks: dropout masks drawn once per (re)training and held fixed, prediction = mean and
+ * unbiased variance over the members, mean Jacobian by reverse sweeps (csrc/sx_mlp.hpp; one particle per lane). */
+#define SX_MLP_MAX_HIDDEN 4      /* hidden layers */
+#define SX_MLP_MAX_WIDTH 64      /* hidden units per layer (the reference's default network is 64 x 64) */
+typedef struct sx_mlp_model {
+    int32_t n_s, n_u;
+    int32_t n_hidden;            /* L */
+    int32_t n_out;               /* rows of the output layer (>= n_s; the first n_s are the predicted means) */
+    int32_t n_samples;           /* S ensemble members (mc_dropout_num_samples) */
+    int32_t predict_std;         /* 1: outputs n_s .. 2 n_s - 1 are log standard deviations; the variance gains the members'
+                                    mean exp(2 log std): the expectation of dropout_ssm_cem.py:106-109 over its fresh noise */
+    int32_t width[SX_MLP_MAX_HIDDEN + 1];   /* width[0] = D, width[l] = hidden layer l */
+    const double* net;           /* dev: W_1 [w1 x D] row-major, b_1, ..., W_L, b_L, W_out [n_out x w_L], b_out */
+    const double* masks;         /* dev [S x (width[0] + ... + width[L])]: the multipliers of the input and of every hidden
+                                    layer's activations (0 or 1 / keep for Bernoulli dropout, relaxed values for concrete) */
+} sx_mlp_model;
+/* Posterior at z dev [P x D]: same outputs as sx_gp_predict.  Replaces McDropoutSSM / GalConcreteDropoutSSM.predict_*
+ * (dropout_ssm_cem.py:79-112, gal_concrete_dropout.py:164-196). */
+int sx_mlp_predict(const sx_mlp_model* model, const double* z, int P, double* mean, double* var, double* jac, void* stream);
+/* The CEM particle rollout over the ensemble: same arguments and outputs as sx_cem_rollout (no workspace). */
+int sx_cem_rollout_mlp(const sx_mlp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
+                       const double* mean, const double* std, const double* noise, double* actions, double* traj,
+                       double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream);
+
 /* Optional kernel timer -- measurement support, not part of the reference's surface (it has no profiler: SURVEY.md 5).
  * While enabled, the launches of the path's kernels (every `sx_profile_stride`-th of each kind) are bracketed by a pair of
  * hipEventRecord on the stream the kernel is launched on (at most `max_launches` launches are recorded); sx_profile_collect synchronises those events and returns
@@ -135,7 +160,8 @@ int sx_cem_rollout_feat(const sx_feat_model* model, const sx_env* env, int E, in
 #define SX_PROF_TRMM_BIG 3       /* trmm_reduce_kernel (large-N path) */
 #define SX_PROF_STEP_BIG 4       /* step_big_kernel    (large-N path) */
 #define SX_PROF_ROLLOUT_FEAT 5   /* cem_rollout_feat_kernel (degenerate-kernel GPs) */
-#define SX_PROF_KINDS 6
+#define SX_PROF_ROLLOUT_MLP 6    /* cem_rollout_mlp_kernel (MC-dropout ensembles) */
+#define SX_PROF_KINDS 7
 int sx_profile_enable(int max_launches);
 int sx_profile_stride(int every);   /* time every n-th launch of a kernel class only (default 1): an event pair costs the
                                        launch path a few microseconds, which a 130 us kernel notices */

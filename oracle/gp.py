@@ -183,3 +183,51 @@ class FeatureGP:
         for d in range(self.n_s):
             out[d] = -0.5 * self.Y[:, d] @ self.alpha[d] - np.log(np.diag(self.L[d])).sum() - 0.5 * self.n * np.log(2 * np.pi)
         return out
+
+
+class DropoutEnsemble:
+    """MC-dropout state-space model with FROZEN masks (reference ssm_cem/dropout_ssm_cem.py, gal_concrete_dropout.py;
+    the `bnn` package is absent and the reference's masks come from torch's RNG: values PARITY UNPINNED): an ensemble of S
+    thinned ReLU networks,
+        a_0 = m_0^s * z,   a_l = relu(W_l a_{l-1} + b_l) * m_l^s,   out^s = W_out a_L + b_out,
+    mean / unbiased variance over the members of the first n_s outputs (dropout_ssm_cem.py:100-112: `preds.mean(dim=0)`,
+    `preds.var(dim=0)`), analytic Jacobian of the mean.  With `predict_std` the outputs n_s .. 2 n_s - 1 are log standard
+    deviations and the variance gains their mean square: the expectation, over the reference's fresh aleatoric noise
+    `pred_log_stds.exp() * randn`, of the sample variance it computes (:106-109).
+    layers = [(W, b), ...] hidden layers then the output layer; masks [S x (D + sum of hidden widths)]."""
+
+    def __init__(self, layers, masks, n_s, predict_std=False):
+        self.layers = [(np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64)) for W, b in layers]
+        self.masks = np.asarray(masks, dtype=np.float64)
+        self.n_s, self.predict_std = n_s, predict_std
+        self.widths = [self.layers[0][0].shape[1]] + [W.shape[0] for W, _ in self.layers[:-1]]
+        assert self.masks.shape[1] == sum(self.widths)
+
+    def predict(self, z, jacobians=True):
+        z = np.asarray(z, dtype=np.float64)
+        P, D = z.shape
+        S = self.masks.shape[0]
+        outs = np.empty((S, P, self.layers[-1][0].shape[0]))
+        jac = np.zeros((P, self.n_s, D)) if jacobians else None
+        offs = np.cumsum([0] + self.widths)
+        for s in range(S):
+            m = [self.masks[s, offs[i]:offs[i + 1]] for i in range(len(self.widths))]
+            a = z * m[0]
+            pres = []
+            for l, (W, b) in enumerate(self.layers[:-1]):
+                pre = a @ W.T + b
+                pres.append(pre)
+                a = np.maximum(pre, 0.0) * m[l + 1]
+            Wo, bo = self.layers[-1]
+            outs[s] = a @ Wo.T + bo
+            if jacobians:
+                G = np.broadcast_to(Wo[:self.n_s][None], (P, self.n_s, Wo.shape[1])).copy()      # d out / d a_L
+                for l in range(len(self.layers) - 2, -1, -1):
+                    G = G * (m[l + 1] * (pres[l] > 0))[:, None, :]                              # -> d / d pre_l
+                    G = G @ self.layers[l][0]                                                    # -> d / d a_{l-1}
+                jac += G * m[0][None, None, :]
+        mean = outs[:, :, :self.n_s].mean(0)
+        var = outs[:, :, :self.n_s].var(0, ddof=1) if S > 1 else np.zeros_like(mean)
+        if self.predict_std:
+            var = var + np.exp(2.0 * outs[:, :, self.n_s:2 * self.n_s]).mean(0)
+        return mean, var, (jac / S if jacobians else None)

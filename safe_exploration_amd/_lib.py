@@ -13,15 +13,18 @@ SX_MAX_M = 16
 SX_TILE = 16
 SX_FEAT_MAX_WIDTH = 32
 SX_FEAT_MAX_LAYERS = 3
+SX_MLP_MAX_HIDDEN = 4
+SX_MLP_MAX_WIDTH = 64
 
 SX_OK, SX_ERR_ARG, SX_ERR_UNSUPPORTED, SX_ERR_LAUNCH = 0, 1, 2, 3
 SX_STATUS_NAN, SX_STATUS_ZERO_FIX, SX_STATUS_UB_NONPOS, SX_STATUS_NOT_PD = 1, 2, 4, 8
 SX_OBJ_NEG_VARIANCE, SX_OBJ_AFFINE_ABS = 0, 1
 SX_CON_TERMINAL, SX_CON_ALL_STATES = 0, 1
-SX_PROF_ROLLOUT_FUSED, SX_PROF_RANK, SX_PROF_KSTAR_BIG, SX_PROF_TRMM_BIG, SX_PROF_STEP_BIG, SX_PROF_ROLLOUT_FEAT = range(6)
+SX_PROF_ROLLOUT_FUSED, SX_PROF_RANK, SX_PROF_KSTAR_BIG, SX_PROF_TRMM_BIG, SX_PROF_STEP_BIG, SX_PROF_ROLLOUT_FEAT, SX_PROF_ROLLOUT_MLP = range(7)
 PROF_KERNELS = {SX_PROF_ROLLOUT_FUSED: 'cem_rollout_kernel', SX_PROF_RANK: 'cem_rank_kernel',
                 SX_PROF_KSTAR_BIG: 'kstar_big_kernel', SX_PROF_TRMM_BIG: 'trmm_reduce_kernel',
-                SX_PROF_STEP_BIG: 'step_big_kernel', SX_PROF_ROLLOUT_FEAT: 'cem_rollout_feat_kernel'}
+                SX_PROF_STEP_BIG: 'step_big_kernel', SX_PROF_ROLLOUT_FEAT: 'cem_rollout_feat_kernel',
+                SX_PROF_ROLLOUT_MLP: 'cem_rollout_mlp_kernel'}
 SX_ACTION_VIOLATION_COST, SX_STATE_VIOLATION_COST = 3.0, 10.0
 
 _ERR = {SX_ERR_ARG: 'bad argument (null pointer, non-positive size or inconsistent shapes)',
@@ -40,6 +43,12 @@ class SxFeatModel(Structure):
     _fields_ = [('n_s', c_int32), ('n_u', c_int32), ('n_feat', c_int32), ('n_layers', c_int32), ('normalise', c_int32),
                 ('width', c_int32 * (SX_FEAT_MAX_LAYERS + 1)), ('prelu', c_double), ('noise', c_double * SX_MAX_NS),
                 ('net', c_void_p), ('wbar', c_void_p), ('minv', c_void_p)]
+
+
+class SxMlpModel(Structure):
+    _fields_ = [('n_s', c_int32), ('n_u', c_int32), ('n_hidden', c_int32), ('n_out', c_int32), ('n_samples', c_int32),
+                ('predict_std', c_int32), ('width', c_int32 * (SX_MLP_MAX_HIDDEN + 1)), ('net', c_void_p),
+                ('masks', c_void_p)]
 
 
 class SxEnv(Structure):
@@ -69,6 +78,8 @@ SIGNATURES = {
     'sx_feat_fit': (c_int, [POINTER(SxFeatModel), c_void_p, c_void_p, c_int, POINTER(c_double)] + [c_void_p] * 5),
     'sx_feat_predict': (c_int, [POINTER(SxFeatModel), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sx_cem_rollout_feat': (c_int, [POINTER(SxFeatModel), POINTER(SxEnv), c_int, c_int, c_int] + [c_void_p] * 12),
+    'sx_mlp_predict': (c_int, [POINTER(SxMlpModel), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'sx_cem_rollout_mlp': (c_int, [POINTER(SxMlpModel), POINTER(SxEnv), c_int, c_int, c_int] + [c_void_p] * 12),
     'sx_onestep_reach': (c_int, [POINTER(SxEnv), c_int] + [c_void_p] * 11),
     'sx_polytope_distance': (c_int, [POINTER(SxEnv), c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p,
                                      c_void_p]),

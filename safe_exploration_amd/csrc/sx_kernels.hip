@@ -19,6 +19,7 @@
 #include "sx_rollout.hpp"
 #include "sx_rank.hpp"
 #include "sx_feat.hpp"
+#include "sx_mlp.hpp"
 
 namespace sx {
 
@@ -639,6 +640,34 @@ static int launch_rollout_feat(const sx_feat_model* m, const sx_env* env, const 
 }
 }  // namespace sx
 
+namespace sx {
+template <int NS, int NU>
+static int launch_mlp_predict(const sx_mlp_model* m, const double* z, int P, double* mean, double* var, double* jac,
+                              hipStream_t stream) {
+    const MlpConst mc = make_mlp_const(m);
+    const size_t lds = mlp_lds_doubles(mc.n_hidden, mc.wmax) * sizeof(double);
+    if (int rc = allow_lds(mlp_predict_kernel<NS, NU>, lds)) return rc;
+    hipLaunchKernelGGL((mlp_predict_kernel<NS, NU>), dim3((P + kMlpLanes - 1) / kMlpLanes), dim3(kMlpLanes), lds, stream, mc, z,
+                       P, mean, var, jac);
+    return check_launch();
+}
+
+template <int NS, int NU>
+static int launch_rollout_mlp(const sx_mlp_model* m, const sx_env* env, const FeatRolloutPtrs& rp, hipStream_t stream) {
+    const MlpConst mc = make_mlp_const(m);
+    ReachConst<NS, NU> rc;
+    if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
+    CostConst<SX_MAX_M, NS, NU> cc;
+    make_cost_const<NS, NU>(env, cc);
+    const size_t lds = mlp_lds_doubles(mc.n_hidden, mc.wmax) * sizeof(double);
+    if (int r = allow_lds(cem_rollout_mlp_kernel<NS, NU>, lds)) return r;
+    const int64_t total = (int64_t)rp.E * rp.P;
+    launch(SX_PROF_ROLLOUT_MLP, cem_rollout_mlp_kernel<NS, NU>, dim3((unsigned)((total + kMlpLanes - 1) / kMlpLanes)),
+           dim3(kMlpLanes), lds, stream, mc, rc, cc, rp);
+    return check_launch();
+}
+}  // namespace sx
+
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
@@ -1054,6 +1083,39 @@ int sx_cem_rollout_feat(const sx_feat_model* model, const sx_env* env, int E, in
     if (env->m <= 0 || env->m > SX_MAX_M) return SX_ERR_UNSUPPORTED;
     sx::FeatRolloutPtrs rp{x0, q0, mean, std, noise, actions, traj, sigma, obj_cost, con_cost, status, E, P, H};
 #define CALL(NS, NU) sx::launch_rollout_feat<NS, NU>(model, env, rp, (hipStream_t)stream)
+    SX_DISPATCH(model->n_s, model->n_u, CALL);
+#undef CALL
+}
+
+static bool mlp_model_ok(const sx_mlp_model* m) {
+    if (!m || m->n_s <= 0 || m->n_s > SX_MAX_NS || m->n_u <= 0 || m->n_u > SX_MAX_NU) return false;
+    if (m->n_hidden < 0 || m->n_hidden > SX_MLP_MAX_HIDDEN || m->n_out < m->n_s || m->n_samples <= 0) return false;
+    if (m->predict_std && m->n_out < 2 * m->n_s) return false;
+    if (m->width[0] != m->n_s + m->n_u || !m->net || !m->masks) return false;
+    for (int l = 1; l <= m->n_hidden; ++l)
+        if (m->width[l] <= 0 || m->width[l] > SX_MLP_MAX_WIDTH) return false;
+    return true;
+}
+
+int sx_mlp_predict(const sx_mlp_model* model, const double* z, int P, double* mean, double* var, double* jac, void* stream) {
+    if (!mlp_model_ok(model) || P < 0) return SX_ERR_ARG;
+    if (P == 0) return SX_OK;
+    if (!z || !mean || !var) return SX_ERR_ARG;
+#define CALL(NS, NU) sx::launch_mlp_predict<NS, NU>(model, z, P, mean, var, jac, (hipStream_t)stream)
+    SX_DISPATCH(model->n_s, model->n_u, CALL);
+#undef CALL
+}
+
+int sx_cem_rollout_mlp(const sx_mlp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
+                       const double* mean, const double* std, const double* noise, double* actions, double* traj,
+                       double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream) {
+    if (!mlp_model_ok(model) || !env || !x0 || !actions || !obj_cost || !con_cost || !status) return SX_ERR_ARG;
+    if (E <= 0 || P <= 0 || H <= 0) return SX_ERR_ARG;
+    if (noise && (!mean || !std)) return SX_ERR_ARG;
+    if (model->n_s != env->n_s || model->n_u != env->n_u) return SX_ERR_ARG;
+    if (env->m <= 0 || env->m > SX_MAX_M) return SX_ERR_UNSUPPORTED;
+    sx::FeatRolloutPtrs rp{x0, q0, mean, std, noise, actions, traj, sigma, obj_cost, con_cost, status, E, P, H};
+#define CALL(NS, NU) sx::launch_rollout_mlp<NS, NU>(model, env, rp, (hipStream_t)stream)
     SX_DISPATCH(model->n_s, model->n_u, CALL);
 #undef CALL
 }

@@ -266,9 +266,9 @@ class CemSafeMPC(SafeMPC):
     def _solver(self):
         if self._injected_mpc:
             return self._mpc
-        if not isinstance(self._ssm, GpCemSSM):
-            raise NotImplementedError('the fused CEM solver needs the HIP-backed GpCemSSM (exact GP); other CemSSMs '
-                                      'are outside the accelerated path')
+        if getattr(self._ssm, 'kernel_family', None) not in ('rbf', 'feature', 'mlp'):
+            raise NotImplementedError('the fused CEM solver needs a HIP-backed CemSSM (GpCemSSM, McDropoutSSM, '
+                                      'GalConcreteDropoutSSM); other CemSSMs are outside the accelerated path')
         # the problem constants only change when the environment moves its objective (the pendulum's target angle,
         # environments.py:505-510): probe the hook at two fixed points and rebuild sx_env only when the answers change
         probe = self._env_objective_cost_func(self._objective_probe)

@@ -51,7 +51,9 @@ def test_struct_layouts_match_c(tmp_path):
                    'printf("%d %d %d %d %d\\n", SX_MAX_NS, SX_MAX_NU, SX_MAX_M, SX_TILE, SX_WAVES);'
                    'printf("%zu %zu %zu %zu %zu %d %d\\n", sizeof(sx_feat_model), offsetof(sx_feat_model, width),'
                    'offsetof(sx_feat_model, prelu), offsetof(sx_feat_model, noise), offsetof(sx_feat_model, minv),'
-                   'SX_FEAT_MAX_WIDTH, SX_FEAT_MAX_LAYERS);return 0;}')
+                   'SX_FEAT_MAX_WIDTH, SX_FEAT_MAX_LAYERS);'
+                   'printf("%zu %zu %zu %zu %d %d\\n", sizeof(sx_mlp_model), offsetof(sx_mlp_model, predict_std),'
+                   'offsetof(sx_mlp_model, width), offsetof(sx_mlp_model, masks), SX_MLP_MAX_HIDDEN, SX_MLP_MAX_WIDTH);return 0;}')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
@@ -62,6 +64,9 @@ def test_struct_layouts_match_c(tmp_path):
     Fm = _lib.SxFeatModel
     want += [ctypes.sizeof(Fm), Fm.width.offset, Fm.prelu.offset, Fm.noise.offset, Fm.minv.offset, _lib.SX_FEAT_MAX_WIDTH,
              _lib.SX_FEAT_MAX_LAYERS]
+    Mm = _lib.SxMlpModel
+    want += [ctypes.sizeof(Mm), Mm.predict_std.offset, Mm.width.offset, Mm.masks.offset, _lib.SX_MLP_MAX_HIDDEN,
+             _lib.SX_MLP_MAX_WIDTH]
     assert got == want
 
 

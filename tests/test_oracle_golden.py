@@ -249,3 +249,29 @@ def test_degenerate_kernel_gp_kernel_space_equals_weight_space():
             quad = (Y[:, d] @ Y[:, d] - (phi_x.T @ Y[:, d]) @ wbar) / noise[d]
             logdet = (50 - F) * np.log(noise[d]) + F * np.log(c[d]) + np.linalg.slogdet(A)[1]
             np.testing.assert_allclose(gp.mll()[d], -0.5 * quad - 0.5 * logdet - 25 * np.log(2 * np.pi), rtol=1e-9)
+
+
+def test_dropout_ensemble_oracle():
+    """oracle.gp.DropoutEnsemble (MC-dropout SSMs with frozen masks, dropout_ssm_cem.py:96-112): mean / unbiased variance
+    over the members, analytic mean Jacobian == numeric, the aleatoric term of predict_std, one member == a plain network."""
+    from oracle.gp import DropoutEnsemble
+    rng = np.random.default_rng(4)
+    layers = [(rng.normal(size=(6, 3)), rng.normal(size=6)), (rng.normal(size=(5, 6)), rng.normal(size=5)),
+              (rng.normal(size=(4, 5)) * 0.3, rng.normal(size=4) * 0.3)]
+    masks = (rng.random((9, 3 + 6 + 5)) > 0.2) / 0.8
+    ens = DropoutEnsemble(layers, masks, 2, predict_std=True)
+    z = rng.normal(size=(6, 3))
+    mean, var, jac = ens.predict(z)
+    for c in range(3):
+        dz = np.zeros(3); dz[c] = 1e-6
+        np.testing.assert_allclose(jac[:, :, c], (ens.predict(z + dz, False)[0] - ens.predict(z - dz, False)[0]) / 2e-6,
+                                   rtol=1e-5, atol=1e-7)
+    plain = DropoutEnsemble(layers, masks, 2, predict_std=False)
+    m2, v2, _ = plain.predict(z)
+    np.testing.assert_array_equal(m2, mean)
+    assert (var > v2).all()                                           # + mean exp(2 log std)
+    one = DropoutEnsemble(layers, np.ones((1, 14)), 2)
+    m1, v1, _ = one.predict(z)
+    h = np.maximum(np.maximum(z @ layers[0][0].T + layers[0][1], 0) @ layers[1][0].T + layers[1][1], 0)
+    np.testing.assert_allclose(m1, (h @ layers[2][0].T + layers[2][1])[:, :2], rtol=1e-13)
+    assert (v1 == 0).all()

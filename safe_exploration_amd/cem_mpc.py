@@ -66,7 +66,8 @@ def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, act
                                            _lib.ptr(con), _lib.ptr(status), _lib.stream_ptr(dev)), 'sx_cem_rollout_feat')
         return dict(actions=actions, obj_cost=obj, con_cost=con, traj=traj, sigma=sigma, status=status)
     if getattr(ssm, 'kernel_family', 'rbf') == 'mlp':
-        # MC-dropout ensembles: one particle per lane over the frozen members (csrc/sx_mlp.hpp)
+        # MC-dropout ensembles over the frozen members: matrix cores for 1-2 hidden layers of <= 64 units
+        # (csrc/sx_mlp_mfma.hpp), one particle per lane otherwise (csrc/sx_mlp.hpp)
         _lib.check(lib.sx_cem_rollout_mlp(ctypes.byref(ssm.mlp_model), ctypes.byref(env), E, P, horizon,
                                           _lib.ptr(x0.contiguous()), _lib.ptr(q0), _lib.ptr(mean), _lib.ptr(std),
                                           _lib.ptr(noise), _lib.ptr(actions), _lib.ptr(traj), _lib.ptr(sigma), _lib.ptr(obj),

@@ -20,6 +20,7 @@
 #include "sx_rank.hpp"
 #include "sx_feat.hpp"
 #include "sx_mlp.hpp"
+#include "sx_mlp_mfma.hpp"
 
 namespace sx {
 
@@ -641,14 +642,46 @@ static int launch_rollout_feat(const sx_feat_model* m, const sx_env* env, const 
 }  // namespace sx
 
 namespace sx {
+// SX_MLP_PATH=valu keeps every network on the one-particle-per-lane kernel (A/B runs; the default is the matrix-core
+// kernel wherever mlp_mfma_ok() holds)
+static bool mlp_use_mfma(const MlpConst& mc) {
+    const char* e = getenv("SX_MLP_PATH");   // read per launch, so that a test can switch between the two kernels
+    return !(e && strcmp(e, "valu") == 0) && mlp_mfma_ok(mc);
+}
+
+template <int NS, int NU, int L>
+static int launch_mlp_predict_mfma(const MlpConst& mc, const double* z, int P, double* mean, double* var, double* jac,
+                                   hipStream_t stream) {
+    const size_t lds = (size_t)MmLds<NS, NS + NU>::total * sizeof(double);
+    if (int rc = allow_lds(mlp_predict_mfma_kernel<NS, NU, L>, lds)) return rc;
+    hipLaunchKernelGGL((mlp_predict_mfma_kernel<NS, NU, L>), dim3((P + kMmTile - 1) / kMmTile), dim3(kMmThreads), lds, stream,
+                       mc, z, P, mean, var, jac);
+    return check_launch();
+}
+
 template <int NS, int NU>
 static int launch_mlp_predict(const sx_mlp_model* m, const double* z, int P, double* mean, double* var, double* jac,
                               hipStream_t stream) {
     const MlpConst mc = make_mlp_const(m);
+    if (mlp_use_mfma(mc)) {
+        if (mc.n_hidden == 1) return launch_mlp_predict_mfma<NS, NU, 1>(mc, z, P, mean, var, jac, stream);
+        return launch_mlp_predict_mfma<NS, NU, 2>(mc, z, P, mean, var, jac, stream);
+    }
     const size_t lds = mlp_lds_doubles(mc.n_hidden, mc.wmax) * sizeof(double);
     if (int rc = allow_lds(mlp_predict_kernel<NS, NU>, lds)) return rc;
     hipLaunchKernelGGL((mlp_predict_kernel<NS, NU>), dim3((P + kMlpLanes - 1) / kMlpLanes), dim3(kMlpLanes), lds, stream, mc, z,
                        P, mean, var, jac);
+    return check_launch();
+}
+
+template <int NS, int NU, int L>
+static int launch_rollout_mlp_mfma(const MlpConst& mc, const ReachConst<NS, NU>& rc, const CostConst<SX_MAX_M, NS, NU>& cc,
+                                   const FeatRolloutPtrs& rp, hipStream_t stream) {
+    const size_t lds = (size_t)MmLds<NS, NS + NU>::total * sizeof(double);
+    if (int r = allow_lds(cem_rollout_mlp_mfma_kernel<NS, NU, L>, lds)) return r;
+    const int64_t total = (int64_t)rp.E * rp.P;
+    launch(SX_PROF_ROLLOUT_MLP, cem_rollout_mlp_mfma_kernel<NS, NU, L>, dim3((unsigned)((total + kMmTile - 1) / kMmTile)),
+           dim3(kMmThreads), lds, stream, mc, rc, cc, rp);
     return check_launch();
 }
 
@@ -659,6 +692,10 @@ static int launch_rollout_mlp(const sx_mlp_model* m, const sx_env* env, const Fe
     if (!make_reach_const<NS, NU>(env, rc)) return SX_ERR_ARG;
     CostConst<SX_MAX_M, NS, NU> cc;
     make_cost_const<NS, NU>(env, cc);
+    if (mlp_use_mfma(mc)) {
+        if (mc.n_hidden == 1) return launch_rollout_mlp_mfma<NS, NU, 1>(mc, rc, cc, rp, stream);
+        return launch_rollout_mlp_mfma<NS, NU, 2>(mc, rc, cc, rp, stream);
+    }
     const size_t lds = mlp_lds_doubles(mc.n_hidden, mc.wmax) * sizeof(double);
     if (int r = allow_lds(cem_rollout_mlp_kernel<NS, NU>, lds)) return r;
     const int64_t total = (int64_t)rp.E * rp.P;

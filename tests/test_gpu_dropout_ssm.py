@@ -1,6 +1,10 @@
 """GPU: the MC-dropout state-space models (reference ssm_cem/dropout_ssm_cem.py, gal_concrete_dropout.py) as
-frozen-mask ensembles (csrc/sx_mlp.hpp) against the numpy oracle (oracle.gp.DropoutEnsemble): posterior, mean Jacobian, CEM
-rollout, full solve, training.  `bnn` is absent and the reference samples through torch's RNG: values parity-unpinned."""
+frozen-mask ensembles against the numpy oracle (oracle.gp.DropoutEnsemble): posterior, mean Jacobian, CEM rollout, full
+solve, training.  Every test runs twice: on the matrix-core kernels (csrc/sx_mlp_mfma.hpp; one or two hidden layers of up to
+64 units) and with SX_MLP_PATH=valu on the one-particle-per-lane kernels (csrc/sx_mlp.hpp) that serve every other network.
+`bnn` is absent and the reference samples through torch's RNG: values parity-unpinned."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +18,18 @@ DEV = 'cuda:0'
 
 def T(x):
     return torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=DEV)
+
+
+@pytest.fixture(autouse=True, params=['mfma', 'valu'])
+def mlp_path(request):
+    """the library reads SX_MLP_PATH at every launch"""
+    old = os.environ.pop('SX_MLP_PATH', None)
+    if request.param == 'valu':
+        os.environ['SX_MLP_PATH'] = 'valu'
+    yield request.param
+    os.environ.pop('SX_MLP_PATH', None)
+    if old is not None:
+        os.environ['SX_MLP_PATH'] = old
 
 
 class Conf:
@@ -40,6 +56,9 @@ def oracle_of(ssm):
 
 
 CASES = [dict(), dict(mc_dropout_on_input=True, mc_dropout_fixed_probability=0.3),
+         dict(mc_dropout_hidden_features=[37], mc_dropout_on_input=True, mc_dropout_predict_std=True,
+              mc_dropout_type='concrete', mc_dropout_num_samples=5),                      # one layer, fewer members than waves
+         dict(mc_dropout_hidden_features=[64, 17], mc_dropout_num_samples=9),
          dict(mc_dropout_type='concrete', mc_dropout_predict_std=True, mc_dropout_on_input=True),
          dict(mc_dropout_hidden_features=[64, 64], mc_dropout_num_samples=30),            # the reference's default network
          dict(mc_dropout_hidden_features=[2, 2, 10, 2], mc_dropout_on_input=True),        # test_ssm_cem.py:90-101
@@ -149,3 +168,38 @@ def test_gal_concrete_dropout_ssm():
         McDropoutSSM(conf(mc_dropout_hidden_features=[128, 128]), 2, 1)
     with pytest.raises(ValueError):
         McDropoutSSM(conf(mc_dropout_type='fixed', mc_dropout_predict_std=True), 2, 1)
+
+
+def test_matrix_core_kernel_equals_lane_kernel_at_the_default_size(mlp_path):
+    """64 x 64, 30 members (experiments/sacred_helper.py:100-102), config 2's particle count: the two kernels against each
+    other, rollout costs and trajectories (different summation orders: tolerance, not bits)."""
+    if mlp_path == 'valu':
+        pytest.skip('one comparison covers both')
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.cem_mpc import cem_rollout
+    from safe_exploration_amd.gp_reachability_pytorch import make_env
+    from safe_exploration_amd.ssm_cem.dropout_ssm_cem import McDropoutSSM
+    spec = problems.pendulum(n_train=100, seed=4, model_error=0.02)
+    ssm = McDropoutSSM(conf(mc_dropout_hidden_features=[64, 64], mc_dropout_num_samples=30, mc_dropout_on_input=True,
+                            mc_dropout_training_iterations=30), 2, 1)
+    ssm.update_model(T(spec.X), T(spec.Y), replace_old=True)
+    env = make_env(2, 1, a=spec.a, b=spec.b, k_fb=spec.k_fb, l_mu=spec.l_mu, l_sigma=spec.l_sigma, beta=spec.beta,
+                   h_mat=spec.h_mat, h_vec=spec.h_vec, u_min=spec.u_min, u_max=spec.u_max)
+    P, H = 4096 + 7, 6
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    noise = torch.randn((1, P, H, 1), dtype=torch.float64, device=DEV, generator=gen)
+    mean = torch.zeros((1, H, 1), dtype=torch.float64, device=DEV)
+    std = torch.full((1, H, 1), 0.2, dtype=torch.float64, device=DEV)
+    x0 = T([[0.02, -0.03]])
+    out = {}
+    for path in ('mfma', 'valu'):
+        if path == 'valu':
+            os.environ['SX_MLP_PATH'] = 'valu'
+        r = cem_rollout(ssm, env, x0, H, mean=mean, std=std, noise=noise, want_traj=True, want_sigma=True)
+        out[path] = {k: r[k].cpu().numpy() for k in ('traj', 'sigma', 'obj_cost', 'con_cost', 'actions')}
+        assert int(r['status'].item()) == 0
+    np.testing.assert_array_equal(out['mfma']['actions'], out['valu']['actions'])
+    np.testing.assert_allclose(out['mfma']['traj'], out['valu']['traj'], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(out['mfma']['sigma'], out['valu']['sigma'], rtol=1e-8, atol=1e-16)
+    np.testing.assert_allclose(out['mfma']['obj_cost'], out['valu']['obj_cost'], rtol=1e-9, atol=1e-13)
+    np.testing.assert_array_equal(out['mfma']['con_cost'], out['valu']['con_cost'])

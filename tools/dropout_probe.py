@@ -1,5 +1,6 @@
 """Times the CEM rollout over an MC-dropout ensemble (the reference's default network: 64 x 64 hidden units, 30 members) at
-config 2's shape (pendulum, 4096 particles, H = 15): cem_rollout_mlp_kernel, one particle per lane."""
+config 2's shape (pendulum, 4096 particles, H = 15): the matrix-core kernel (cem_rollout_mlp_mfma_kernel), and with
+PATHS=mfma,valu also the one-particle-per-lane kernel (cem_rollout_mlp_kernel).  HIDDEN=64,64  P=4096 override the shape."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,11 +27,15 @@ P, H = int(os.environ.get('P', 4096)), 15
 x0 = T([[0.02, -0.03]])
 mean, std = torch.zeros((1, H, 1), dtype=torch.float64, device=dev), torch.full((1, H, 1), 0.1, dtype=torch.float64, device=dev)
 noise = torch.randn((1, P, H, 1), dtype=torch.float64, device=dev)
-for i in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    r = cem_rollout(ssm, env, x0, H, mean=mean, std=std, noise=noise)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    w = [3] + Conf.mc_dropout_hidden_features
-    macs = 30 * (sum(w[i] * w[i + 1] for i in range(len(w) - 1)) + w[-1] * 2) * 3     # forward + 2 reverse sweeps
-    print(f'hidden {Conf.mc_dropout_hidden_features} S=30 P={P} H={H}: {dt*1e3:.2f} ms  {P*H/dt:.3e} particle-steps/s  '
-          f'~{2*macs*P*H/dt/1e12:.2f} TFLOP/s  status {int(r["status"].item())}', flush=True)
+for path in os.environ.get('PATHS', 'mfma').split(','):
+    os.environ.pop('SX_MLP_PATH', None)
+    if path == 'valu':
+        os.environ['SX_MLP_PATH'] = 'valu'
+    for i in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = cem_rollout(ssm, env, x0, H, mean=mean, std=std, noise=noise)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        w = [3] + Conf.mc_dropout_hidden_features
+        macs = 30 * (sum(w[i] * w[i + 1] for i in range(len(w) - 1)) + w[-1] * 2) * 3     # forward + 2 reverse sweeps
+        print(f'{path}: hidden {Conf.mc_dropout_hidden_features} S=30 P={P} H={H}: {dt*1e3:.2f} ms  {P*H/dt:.3e} particle-steps/s  '
+              f'~{2*macs*P*H/dt/1e12:.2f} TFLOP/s algorithmic  status {int(r["status"].item())}', flush=True)

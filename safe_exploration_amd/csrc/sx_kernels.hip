@@ -649,12 +649,12 @@ static bool mlp_use_mfma(const MlpConst& mc) {
     return !(e && strcmp(e, "valu") == 0) && mlp_mfma_ok(mc);
 }
 
-template <int NS, int NU, int L>
+template <int NS, int NU, int L, bool FULL>
 static int launch_mlp_predict_mfma(const MlpConst& mc, const double* z, int P, double* mean, double* var, double* jac,
                                    hipStream_t stream) {
     const size_t lds = (size_t)MmLds<NS, NS + NU>::total * sizeof(double);
-    if (int rc = allow_lds(mlp_predict_mfma_kernel<NS, NU, L>, lds)) return rc;
-    hipLaunchKernelGGL((mlp_predict_mfma_kernel<NS, NU, L>), dim3((P + kMmTile - 1) / kMmTile), dim3(kMmThreads), lds, stream,
+    if (int rc = allow_lds(mlp_predict_mfma_kernel<NS, NU, L, FULL>, lds)) return rc;
+    hipLaunchKernelGGL((mlp_predict_mfma_kernel<NS, NU, L, FULL>), dim3((P + kMmTile - 1) / kMmTile), dim3(kMmThreads), lds, stream,
                        mc, z, P, mean, var, jac);
     return check_launch();
 }
@@ -664,8 +664,12 @@ static int launch_mlp_predict(const sx_mlp_model* m, const double* z, int P, dou
                               hipStream_t stream) {
     const MlpConst mc = make_mlp_const(m);
     if (mlp_use_mfma(mc)) {
-        if (mc.n_hidden == 1) return launch_mlp_predict_mfma<NS, NU, 1>(mc, z, P, mean, var, jac, stream);
-        return launch_mlp_predict_mfma<NS, NU, 2>(mc, z, P, mean, var, jac, stream);
+        const bool full = mlp_mfma_full(mc);
+        if (mc.n_hidden == 1)
+            return full ? launch_mlp_predict_mfma<NS, NU, 1, true>(mc, z, P, mean, var, jac, stream)
+                        : launch_mlp_predict_mfma<NS, NU, 1, false>(mc, z, P, mean, var, jac, stream);
+        return full ? launch_mlp_predict_mfma<NS, NU, 2, true>(mc, z, P, mean, var, jac, stream)
+                    : launch_mlp_predict_mfma<NS, NU, 2, false>(mc, z, P, mean, var, jac, stream);
     }
     const size_t lds = mlp_lds_doubles(mc.n_hidden, mc.wmax) * sizeof(double);
     if (int rc = allow_lds(mlp_predict_kernel<NS, NU>, lds)) return rc;
@@ -674,13 +678,13 @@ static int launch_mlp_predict(const sx_mlp_model* m, const double* z, int P, dou
     return check_launch();
 }
 
-template <int NS, int NU, int L>
+template <int NS, int NU, int L, bool FULL>
 static int launch_rollout_mlp_mfma(const MlpConst& mc, const ReachConst<NS, NU>& rc, const CostConst<SX_MAX_M, NS, NU>& cc,
                                    const FeatRolloutPtrs& rp, hipStream_t stream) {
     const size_t lds = (size_t)MmLds<NS, NS + NU>::total * sizeof(double);
-    if (int r = allow_lds(cem_rollout_mlp_mfma_kernel<NS, NU, L>, lds)) return r;
+    if (int r = allow_lds(cem_rollout_mlp_mfma_kernel<NS, NU, L, FULL>, lds)) return r;
     const int64_t total = (int64_t)rp.E * rp.P;
-    launch(SX_PROF_ROLLOUT_MLP, cem_rollout_mlp_mfma_kernel<NS, NU, L>, dim3((unsigned)((total + kMmTile - 1) / kMmTile)),
+    launch(SX_PROF_ROLLOUT_MLP, cem_rollout_mlp_mfma_kernel<NS, NU, L, FULL>, dim3((unsigned)((total + kMmTile - 1) / kMmTile)),
            dim3(kMmThreads), lds, stream, mc, rc, cc, rp);
     return check_launch();
 }
@@ -693,8 +697,12 @@ static int launch_rollout_mlp(const sx_mlp_model* m, const sx_env* env, const Fe
     CostConst<SX_MAX_M, NS, NU> cc;
     make_cost_const<NS, NU>(env, cc);
     if (mlp_use_mfma(mc)) {
-        if (mc.n_hidden == 1) return launch_rollout_mlp_mfma<NS, NU, 1>(mc, rc, cc, rp, stream);
-        return launch_rollout_mlp_mfma<NS, NU, 2>(mc, rc, cc, rp, stream);
+        const bool full = mlp_mfma_full(mc);
+        if (mc.n_hidden == 1)
+            return full ? launch_rollout_mlp_mfma<NS, NU, 1, true>(mc, rc, cc, rp, stream)
+                        : launch_rollout_mlp_mfma<NS, NU, 1, false>(mc, rc, cc, rp, stream);
+        return full ? launch_rollout_mlp_mfma<NS, NU, 2, true>(mc, rc, cc, rp, stream)
+                    : launch_rollout_mlp_mfma<NS, NU, 2, false>(mc, rc, cc, rp, stream);
     }
     const size_t lds = mlp_lds_doubles(mc.n_hidden, mc.wmax) * sizeof(double);
     if (int r = allow_lds(cem_rollout_mlp_kernel<NS, NU>, lds)) return r;

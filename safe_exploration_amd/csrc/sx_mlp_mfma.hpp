@@ -52,7 +52,8 @@ struct MmLds {
     static constexpr int zbuf = woutp + NS * kMmW;                 // [16][8] query points
     static constexpr int part = zbuf + kMmTile * 8;                // [waves][kSlots][16]
     static constexpr int wmask = part + kMmWaves * kSlots * kMmTile;   // [waves][kMmMaskRow] the current member's masks
-    static constexpr int total = wmask + kMmWaves * kMmMaskRow;
+    static constexpr int state = wmask + kMmWaves * kMmMaskRow;        // [16][NS * NS + 2] rollout: Q, objective, constraint cost
+    static constexpr int total = state + kMmTile * (NS * NS + 2);
 };
 
 struct MmDims {
@@ -81,6 +82,12 @@ __host__ __device__ inline MmDims mm_dims(const MlpConst& mc) {
     d.moff2 = mc.d_in + d.w1;
     d.msum = mc.d_in + d.w1 + d.w2;
     return d;
+}
+// every hidden layer 64 wide: the kernels' straight-line instantiation
+__host__ __device__ inline bool mlp_mfma_full(const MlpConst& mc) {
+    for (int l = 1; l <= mc.n_hidden; ++l)
+        if (mc.width[l] != kMmW) return false;
+    return true;
 }
 
 // element (row, k) of a fragment-pair matrix with `npairs` pairs per row-block -> index in doubles
@@ -131,11 +138,181 @@ __device__ __forceinline__ void mm_pack(const MlpConst& mc, const MmDims& dm, do
 
 #define SX_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+// 1.0 where bit k of `bits` is set, else 0.0 -- as arithmetic on the high word, so that the compiler multiplies by it
+// instead of branching around the LDS reads of the other factor
+__device__ __forceinline__ double mm_gate(unsigned bits, int k) {
+    const int all = (int)(bits << (31 - k)) >> 31;   // 0 or -1
+    return __hiloint2double(all & 0x3ff00000, 0);
+}
+
+// ---- every hidden layer 64 wide (the reference's default): straight-line code --------------------------------------
+// acc[rb] += A[rb][:] . B for the four row-blocks of a 64 x 64 layer: K-pairs outermost, so that the four accumulators
+// are independent chains and the fragments of pair q + 1 are in flight while pair q computes.
+__device__ __forceinline__ void mm_layer64(const v2d* __restrict__ frag, const double (&bop)[16], v4d (&acc)[4]) {
+    constexpr bool FULL = true;
+    constexpr int nrb = 4, npairs = 8;
+    v2d fr[4], nx[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) fr[rb] = (FULL || rb < nrb) ? frag[(rb * 8) * 64] : v2d{0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (FULL || q < npairs) {
+            if (q + 1 < 8) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+                    nx[rb] = (FULL || (rb < nrb && q + 1 < npairs)) ? frag[(rb * 8 + q + 1) * 64] : v2d{0.0, 0.0};
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                if (FULL || rb < nrb) acc[rb] = SX_MFMA(fr[rb].x, bop[2 * q], acc[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                if (FULL || rb < nrb) acc[rb] = SX_MFMA(fr[rb].y, bop[2 * q + 1], acc[rb]);
+            if (q + 1 < 8) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) fr[rb] = nx[rb];
+            }
+            SX_PIN();
+        }
+    }
+}
+
+// acc += A[0][:] . B for ONE row-block (output layer, Jacobian rows): a dependent chain, fragments two pairs ahead
+__device__ __forceinline__ v4d mm_rows16(const v2d* __restrict__ frag, const double (&bop)[16], v4d acc) {
+    constexpr bool FULL = true;
+    constexpr int npairs = 8;
+    v2d fr[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fr[q] = (FULL || q < npairs) ? frag[q * 64] : v2d{0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (FULL || q < npairs) {
+            acc = SX_MFMA(fr[q].x, bop[2 * q], acc);
+            acc = SX_MFMA(fr[q].y, bop[2 * q + 1], acc);
+        }
+    }
+    SX_PIN();
+    return acc;
+}
+
 // One member for the wave's 16 particles.  `zc` is the query point of particle lane & 15, `wm` the member's masks in LDS
 // ([0..7] input, [8 + unit] hidden layer 1, [8 + 64 + unit] hidden layer 2; zero beyond the layer's width).  Returns the
 // output rows (row = (lane >> 4) + 4 r) and, WITH_JAC, d out_d / d z_j at (lane >> 4) + 4 r = j for r = 0, 1.
 template <int NS, int D, int L, bool WITH_JAC>
-__device__ __forceinline__ void mm_member(const MmDims& dm, const double* lds, const double* wm, int lane,
+__device__ __forceinline__ void mm_member_full(const double* lds, const double* wm, int lane, const double (&zc)[D],
+                                               v4d& out, double (&jrow)[NS][2]) {
+    using M = MmLds<NS, D>;
+    constexpr bool FULL = true;
+    const int g = lane >> 4;
+    const v2d* w1a = reinterpret_cast<const v2d*>(lds + M::w1a) + lane;
+    const v2d* w2 = reinterpret_cast<const v2d*>(lds + M::w2) + lane;
+    const v2d* w2t = reinterpret_cast<const v2d*>(lds + M::w2t) + lane;
+    const v2d* wo = reinterpret_cast<const v2d*>(lds + M::wout) + lane;
+    const v2d* w1t = reinterpret_cast<const v2d*>(lds + M::w1t) + lane;
+    const double* wm1 = wm + 8 + g;            // mask of unit 4 kc + g of hidden layer 1 at wm1[4 kc]
+    const double* wm2 = wm + 8 + kMmW + g;
+    constexpr int nrb1 = 4;
+
+    // input rows of the B operand: masked z, then the constant 1 that picks up the bias column
+    double zin[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zin[j] = j < D ? zc[j] * wm[j] : (j == D ? 1.0 : 0.0);
+    const double b0x = g == 0 ? zin[0] : (g == 1 ? zin[1] : (g == 2 ? zin[2] : zin[3]));
+    const double b0y = g == 0 ? zin[4] : (g == 1 ? zin[5] : (g == 2 ? zin[6] : zin[7]));
+
+    // a1 / a2: the activations (B operands of the next layer); on1 / on2: bit kc = unit 4 kc + g is active, which is all
+    // the reverse sweep keeps of them (the masks are read again from LDS: registers)
+    double a1[16], a2[16];
+    unsigned on1 = 0, on2 = 0;
+    {
+        v2d fr[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) fr[rb] = w1a[rb * 64];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            if (FULL || rb < nrb1) {
+                acc = SX_MFMA(fr[rb].x, b0x, acc);
+                if constexpr (D + 1 > 4) acc = SX_MFMA(fr[rb].y, b0y, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double m = wm1[4 * (4 * rb + r)];
+                const double v = fmax(acc[r], 0.0) * m;   // (no select: the compiler would branch around the mask read)
+                a1[4 * rb + r] = v;
+                on1 |= (v > 0.0 ? 1u : 0u) << (4 * rb + r);
+            }
+        }
+        SX_PIN();
+    }
+    if constexpr (L == 2) {
+        v4d acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rb][r] = lds[M::b2 + 16 * rb + 4 * r + g];
+        mm_layer64(w2, a1, acc);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double m = wm2[4 * (4 * rb + r)];
+                const double v = fmax(acc[rb][r], 0.0) * m;
+                a2[4 * rb + r] = v;
+                on2 |= (v > 0.0 ? 1u : 0u) << (4 * rb + r);
+            }
+        SX_PIN();
+    }
+    const double(&al)[16] = L == 2 ? a2 : a1;       // last hidden layer
+    const unsigned onl = L == 2 ? on2 : on1;
+    const double* wml = L == 2 ? wm2 : wm1;
+    {
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = lds[M::bout + 4 * r + g];
+        out = mm_rows16(wo, al, acc);
+    }
+    if constexpr (WITH_JAC) {
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+            double gl[16];   // d out_d / d (pre-activation) of the last hidden layer, B layout
+#pragma unroll
+            for (int kc = 0; kc < 16; ++kc) {
+                const double v = lds[M::woutp + d * kMmW + 4 * kc + g] * wml[4 * kc];
+                gl[kc] = v * mm_gate(onl, kc);
+            }
+            SX_PIN();
+            double g1[16];
+            if constexpr (L == 2) {
+                v4d acc[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb] = v4d{0.0, 0.0, 0.0, 0.0};
+                mm_layer64(w2t, gl, acc);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double m = wm1[4 * (4 * rb + r)];
+                        g1[4 * rb + r] = acc[rb][r] * m * mm_gate(on1, 4 * rb + r);
+                    }
+                SX_PIN();
+            } else {
+#pragma unroll
+                for (int kc = 0; kc < 16; ++kc) g1[kc] = gl[kc];
+            }
+            const v4d acc = mm_rows16(w1t, g1, v4d{0.0, 0.0, 0.0, 0.0});
+            // row j = g + 4 r of W1^T g1 is d out_d / d (masked z_j): the input mask once more (wm[j] = 0 for j >= D)
+            jrow[d][0] = acc[0] * wm[g];
+            jrow[d][1] = acc[1] * wm[g + 4];
+        }
+    }
+}
+
+// (generic widths) One member for the wave's 16 particles: row-block by row-block, run-time (uniform) guards.  `zc` is the query point of particle lane & 15, `wm` the member's masks in LDS
+// ([0..7] input, [8 + unit] hidden layer 1, [8 + 64 + unit] hidden layer 2; zero beyond the layer's width).  Returns the
+// output rows (row = (lane >> 4) + 4 r) and, WITH_JAC, d out_d / d z_j at (lane >> 4) + 4 r = j for r = 0, 1.
+template <int NS, int D, int L, bool WITH_JAC>
+__device__ __forceinline__ void mm_member_generic(const MmDims& dm, const double* lds, const double* wm, int lane,
                                           const double (&zc)[D], v4d& out, double (&jrow)[NS][2]) {
     using M = MmLds<NS, D>;
     const int g = lane >> 4;
@@ -166,7 +343,8 @@ __device__ __forceinline__ void mm_member(const MmDims& dm, const double* lds, c
             if constexpr (D + 1 > 4) acc = SX_MFMA(a.y, b0y, acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double v = acc[r] > 0.0 ? acc[r] * wm1[4 * (4 * rb + r)] : 0.0;
+                const double m = wm1[4 * (4 * rb + r)];
+                const double v = fmax(acc[r], 0.0) * m;   // (no select: the compiler would branch around the mask read)
                 a1[4 * rb + r] = v;
                 on1 |= (v > 0.0 ? 1u : 0u) << (4 * rb + r);
             }
@@ -193,7 +371,8 @@ __device__ __forceinline__ void mm_member(const MmDims& dm, const double* lds, c
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double v = acc[r] > 0.0 ? acc[r] * wm2[4 * (4 * rb + r)] : 0.0;
+                    const double m = wm2[4 * (4 * rb + r)];
+                    const double v = fmax(acc[r], 0.0) * m;   // (no select: the compiler would branch around the mask read)
                     a2[4 * rb + r] = v;
                     on2 |= (v > 0.0 ? 1u : 0u) << (4 * rb + r);
                 }
@@ -229,7 +408,10 @@ __device__ __forceinline__ void mm_member(const MmDims& dm, const double* lds, c
             double gl[16];   // d out_d / d (pre-activation) of the last hidden layer, B layout
 #pragma unroll
             for (int kc = 0; kc < 16; ++kc)
-                gl[kc] = ((onl >> kc) & 1u) ? lds[M::woutp + d * kMmW + 4 * kc + g] * wml[4 * kc] : 0.0;
+            {
+                const double v = lds[M::woutp + d * kMmW + 4 * kc + g] * wml[4 * kc];
+                gl[kc] = v * mm_gate(onl, kc);
+            }
             SX_PIN();
             double g1[16];
             if constexpr (L == 2) {
@@ -246,8 +428,10 @@ __device__ __forceinline__ void mm_member(const MmDims& dm, const double* lds, c
                             }
                         }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            g1[4 * rb + r] = ((on1 >> (4 * rb + r)) & 1u) ? acc[r] * wm1[4 * (4 * rb + r)] : 0.0;
+                        for (int r = 0; r < 4; ++r) {
+                            const double m = wm1[4 * (4 * rb + r)];
+                            g1[4 * rb + r] = acc[r] * m * mm_gate(on1, 4 * rb + r);
+                        }
                         SX_PIN();
                     } else {
 #pragma unroll
@@ -277,7 +461,7 @@ __device__ __forceinline__ void mm_member(const MmDims& dm, const double* lds, c
 
 // The ensemble for one tile: every wave runs its members and leaves its partial sums in LDS (the caller synchronises).
 // slots per wave: [d] mean, [NS + d] M2, [2 NS + d] aleatoric sum, [3 NS + d D + j] Jacobian sum
-template <int NS, int D, int L, bool WITH_JAC>
+template <int NS, int D, int L, bool WITH_JAC, bool FULL>
 __device__ __forceinline__ void mm_ensemble_wave(const MlpConst& mc, const MmDims& dm, double* lds, int wave, int lane,
                                                  const double (&zc)[D]) {
     using M = MmLds<NS, D>;
@@ -299,7 +483,10 @@ __device__ __forceinline__ void mm_ensemble_wave(const MlpConst& mc, const MmDim
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         v4d out;
         double jrow[NS][2];
-        mm_member<NS, D, L, WITH_JAC>(dm, lds, wm, lane, zc, out, jrow);
+        if constexpr (FULL)
+            mm_member_full<NS, D, L, WITH_JAC>(lds, wm, lane, zc, out, jrow);
+        else
+            mm_member_generic<NS, D, L, WITH_JAC>(dm, lds, wm, lane, zc, out, jrow);
         __builtin_amdgcn_wave_barrier();   // (the next member's masks overwrite the row)
         ++n;
         // Welford on row g (r = 0): the mean outputs are rows 0 .. NS - 1 <= 3
@@ -380,7 +567,7 @@ __device__ __forceinline__ void mm_merge(const MmDims& dm, const double* lds, in
     }
 }
 
-template <int NS, int NU, int L>
+template <int NS, int NU, int L, bool FULL>
 __global__ __launch_bounds__(kMmThreads) void mlp_predict_mfma_kernel(MlpConst mc, const double* __restrict__ zin, int P,
                                                                       double* __restrict__ mean, double* __restrict__ var,
                                                                       double* __restrict__ jac) {
@@ -397,9 +584,9 @@ __global__ __launch_bounds__(kMmThreads) void mlp_predict_mfma_kernel(MlpConst m
     for (int j = 0; j < D; ++j) zc[j] = gc < P ? zin[gc * D + j] : 0.0;
     __syncthreads();
     if (jac)
-        mm_ensemble_wave<NS, D, L, true>(mc, dm, mm_smem, wave, lane, zc);
+        mm_ensemble_wave<NS, D, L, true, FULL>(mc, dm, mm_smem, wave, lane, zc);
     else
-        mm_ensemble_wave<NS, D, L, false>(mc, dm, mm_smem, wave, lane, zc);
+        mm_ensemble_wave<NS, D, L, false, FULL>(mc, dm, mm_smem, wave, lane, zc);
     __syncthreads();
     if (tid < kMmTile && base + tid < P) {
         double m[NS], v[NS], jc[NS][D];
@@ -421,7 +608,7 @@ __global__ __launch_bounds__(kMmThreads) void mlp_predict_mfma_kernel(MlpConst m
 }
 
 // the CEM particle rollout over the ensemble (arguments as FeatRolloutPtrs; results as cem_rollout_mlp_kernel)
-template <int NS, int NU, int L>
+template <int NS, int NU, int L, bool FULL>
 __global__ __launch_bounds__(kMmThreads) void cem_rollout_mlp_mfma_kernel(MlpConst mc, ReachConst<NS, NU> rc,
                                                                           CostConst<SX_MAX_M, NS, NU> cc,
                                                                           FeatRolloutPtrs rp) {
@@ -433,7 +620,8 @@ __global__ __launch_bounds__(kMmThreads) void cem_rollout_mlp_mfma_kernel(MlpCon
     const MmDims dm = mm_dims(mc);
     mm_pack<NS, D>(mc, dm, mm_smem, tid);
 
-    // particle state: lanes 0-15 of wave 0
+    // Particle state: owned by lanes 0-15 of wave 0, but kept in LDS between the steps (the centre and the action in the
+    // query-point buffer, Q and the two costs beside it), so that no register is held across the members' matrix work.
     const bool owner = tid < kMmTile;
     const int64_t total = (int64_t)rp.E * rp.P;
     const int64_t g = (int64_t)blockIdx.x * kMmTile + (tid & 15);
@@ -441,12 +629,11 @@ __global__ __launch_bounds__(kMmThreads) void cem_rollout_mlp_mfma_kernel(MlpCon
     const int64_t gg = g < total ? g : 0;
     const int e = (int)(gg / rp.P);
     const int H = rp.H;
-    double p[NS], Q[NS][NS], u[NU];
     bool have_q = rp.q0 != nullptr;    // (uniform)
-    double obj = 0.0, con = 0.0;
     int st = 0;
     double* zbuf = mm_smem + M::zbuf;
-    auto publish = [&](int t) {        // the action of step t and the query point (p, u) -> LDS
+    double* sbuf = mm_smem + M::state + (tid & 15) * (NS * NS + 2);
+    auto publish = [&](int t, const double (&p)[NS]) {        // the action of step t and the query point (p, u) -> LDS
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
             const int64_t gi = (gg * H + t) * NU + c;
@@ -457,34 +644,45 @@ __global__ __launch_bounds__(kMmThreads) void cem_rollout_mlp_mfma_kernel(MlpCon
             } else {
                 a = rp.actions[gi];
             }
-            u[c] = a;
+            zbuf[tid * 8 + NS + c] = a;
         }
 #pragma unroll
         for (int j = 0; j < NS; ++j) zbuf[tid * 8 + j] = p[j];
-#pragma unroll
-        for (int c = 0; c < NU; ++c) zbuf[tid * 8 + NS + c] = u[c];
     };
     if (owner) {
+        double p[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             p[i] = rp.x0[(int64_t)e * NS + i];
 #pragma unroll
-            for (int j = 0; j < NS; ++j) Q[i][j] = have_q ? rp.q0[((int64_t)e * NS + i) * NS + j] : 0.0;
+            for (int j = 0; j < NS; ++j) sbuf[i * NS + j] = have_q ? rp.q0[((int64_t)e * NS + i) * NS + j] : 0.0;
         }
-        publish(0);
+        sbuf[NS * NS] = sbuf[NS * NS + 1] = 0.0;
+        publish(0, p);
     }
     for (int t = 0; t < H; ++t) {
         __syncthreads();   // weights packed (t = 0), query points published
-        double zc[D];
+        {
+            double zc[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) zc[j] = zbuf[(lane & 15) * 8 + j];
-        if (have_q)
-            mm_ensemble_wave<NS, D, L, true>(mc, dm, mm_smem, wave, lane, zc);
-        else
-            mm_ensemble_wave<NS, D, L, false>(mc, dm, mm_smem, wave, lane, zc);
+            for (int j = 0; j < D; ++j) zc[j] = zbuf[(lane & 15) * 8 + j];
+            if (have_q)
+                mm_ensemble_wave<NS, D, L, true, FULL>(mc, dm, mm_smem, wave, lane, zc);
+            else
+                mm_ensemble_wave<NS, D, L, false, FULL>(mc, dm, mm_smem, wave, lane, zc);
+        }
         __syncthreads();   // partial sums complete; every wave has read its query points
         if (owner) {
-            double mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
+            double p[NS], Q[NS][NS], u[NU], mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                p[i] = zbuf[tid * 8 + i];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) Q[i][j] = sbuf[i * NS + j];
+            }
+#pragma unroll
+            for (int c = 0; c < NU; ++c) u[c] = zbuf[tid * 8 + NS + c];
+            double obj = sbuf[NS * NS], con = sbuf[NS * NS + 1];
             if (have_q) {
                 mm_merge<NS, D, true>(dm, mm_smem, tid, mean, var, jac);
                 reach_ellipsoid<NS, NU>(rc, p, Q, u, mean, var, jac, p1, Q1, st);
@@ -515,18 +713,18 @@ __global__ __launch_bounds__(kMmThreads) void cem_rollout_mlp_mfma_kernel(MlpCon
                 for (int i = 0; i < NS; ++i) rp.sigma[(g * H + t) * NS + i] = var[i];
             }
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                p[i] = p1[i];
+            for (int i = 0; i < NS; ++i)
 #pragma unroll
-                for (int j = 0; j < NS; ++j) Q[i][j] = Q1[i][j];
-            }
-            if (t + 1 < H) publish(t + 1);
+                for (int j = 0; j < NS; ++j) sbuf[i * NS + j] = Q1[i][j];
+            sbuf[NS * NS] = obj;
+            sbuf[NS * NS + 1] = con;
+            if (t + 1 < H) publish(t + 1, p1);
         }
         have_q = true;
     }
     if (valid) {
-        rp.obj_cost[g] = obj;
-        rp.con_cost[g] = con;
+        rp.obj_cost[g] = sbuf[NS * NS];
+        rp.con_cost[g] = sbuf[NS * NS + 1];
         if (st) atomicOr(rp.status, st);
     }
 }

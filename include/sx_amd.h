@@ -127,7 +127,9 @@ int sx_cem_rollout_feat(const sx_feat_model* model, const sx_env* env, int E, in
 
 /* ---- MC-dropout state-space models: ssm_cem/dropout_ssm_cem.py, gal_concrete_dropout.py ----
  * An ensemble of S thinned ReLU networks: dropout masks drawn once per (re)training and held fixed, prediction = mean and
- * unbiased variance over the members, mean Jacobian by reverse sweeps (csrc/sx_mlp.hpp; one particle per lane). */
+ * unbiased variance over the members, mean Jacobian by reverse sweeps.  One or two hidden layers of <= 64 units run on the
+ * f64 matrix cores (csrc/sx_mlp_mfma.hpp: a 16-particle tile per workgroup, a member per wave, activations in registers);
+ * other shapes one particle per lane (csrc/sx_mlp.hpp).  SX_MLP_PATH=valu in the environment forces the latter (A/B runs). */
 #define SX_MLP_MAX_HIDDEN 4      /* hidden layers */
 #define SX_MLP_MAX_WIDTH 64      /* hidden units per layer (the reference's default network is 64 x 64) */
 typedef struct sx_mlp_model {
@@ -160,7 +162,7 @@ int sx_cem_rollout_mlp(const sx_mlp_model* model, const sx_env* env, int E, int 
 #define SX_PROF_TRMM_BIG 3       /* trmm_reduce_kernel (large-N path) */
 #define SX_PROF_STEP_BIG 4       /* step_big_kernel    (large-N path) */
 #define SX_PROF_ROLLOUT_FEAT 5   /* cem_rollout_feat_kernel (degenerate-kernel GPs) */
-#define SX_PROF_ROLLOUT_MLP 6    /* cem_rollout_mlp_kernel (MC-dropout ensembles) */
+#define SX_PROF_ROLLOUT_MLP 6    /* cem_rollout_mlp_mfma_kernel / cem_rollout_mlp_kernel (MC-dropout ensembles) */
 #define SX_PROF_KINDS 7
 int sx_profile_enable(int max_launches);
 int sx_profile_stride(int every);   /* time every n-th launch of a kernel class only (default 1): an event pair costs the

@@ -8,10 +8,10 @@
 // pass in gal_concrete_dropout.py:61-75 -- and differentiates with autograd; bnn is absent: values parity-unpinned, and
 // freezing the concrete noise is a documented deviation)
 //
-// One particle per LANE, members in sequence: the weights and masks are wave-uniform (scalar loads), the member's hidden
-// pre-activations sit in LDS as [unit][lane].  The reference's default network (64 x 64, 30 members) is ~0.8 MFLOP per
-// particle-step on plain VALU instructions; a matrix-core version would batch the members' 64 x 64 layers as GEMMs over the
-// particle tile (DESIGN.md "Next").
+// THIS FILE: one particle per LANE, members in sequence: the weights and masks are wave-uniform (scalar loads), the member's
+// hidden pre-activations sit in LDS as [unit][lane].  It serves the shapes the matrix-core kernels of sx_mlp_mfma.hpp do not
+// (no hidden layer, three or four hidden layers) and is their A/B reference (SX_MLP_PATH=valu); the reference's default
+// network (64 x 64, 30 members; ~0.8 MFLOP per particle-step) runs 350x faster there.
 #pragma once
 #include <hip/hip_runtime.h>
 

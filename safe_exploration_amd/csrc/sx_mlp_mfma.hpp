@@ -471,13 +471,22 @@ __device__ __forceinline__ void mm_ensemble_wave(const MlpConst& mc, const MmDim
     for (int d = 0; d < NS; ++d) jsum[d][0] = jsum[d][1] = 0.0;
     int n = 0;
     double* wm = lds + M::wmask + wave * kMmMaskRow;
-    for (int s = wave; s < dm.n_samples; s += kMmWaves) {
-        // this member's masks: global -> this wave's LDS row (padding stays zero, see mm_pack).  A wave's LDS
-        // operations execute in order, so no barrier is needed between these writes and the reads in mm_member.
+    // A member's masks go global -> registers -> this wave's LDS row (padding stays zero, see mm_pack); the loads for
+    // the NEXT member are issued before the current one computes, so their latency is never waited for.  A wave's LDS
+    // operations execute in order: no barrier between these writes and the reads in mm_member, only compiler fences.
+    double mreg[3] = {0.0, 0.0, 0.0};
+    auto fetch = [&](int s) {
         const double* mk = mc.masks + (size_t)s * dm.msum;
-        if (lane < D) wm[lane] = mk[lane];
-        if (lane < dm.w1) wm[8 + lane] = mk[dm.moff1 + lane];
-        if (L == 2 && lane < dm.w2) wm[8 + kMmW + lane] = mk[dm.moff2 + lane];
+        if (lane < D) mreg[0] = mk[lane];
+        if (lane < dm.w1) mreg[1] = mk[dm.moff1 + lane];
+        if (L == 2 && lane < dm.w2) mreg[2] = mk[dm.moff2 + lane];
+    };
+    if (wave < dm.n_samples) fetch(wave);
+    for (int s = wave; s < dm.n_samples; s += kMmWaves) {
+        if (lane < D) wm[lane] = mreg[0];
+        if (lane < dm.w1) wm[8 + lane] = mreg[1];
+        if (L == 2 && lane < dm.w2) wm[8 + kMmW + lane] = mreg[2];
+        if (s + kMmWaves < dm.n_samples) fetch(s + kMmWaves);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -572,7 +581,6 @@ __global__ __launch_bounds__(kMmThreads) void mlp_predict_mfma_kernel(MlpConst m
                                                                       double* __restrict__ mean, double* __restrict__ var,
                                                                       double* __restrict__ jac) {
     constexpr int D = NS + NU;
-    using M = MmLds<NS, D>;
     extern __shared__ __attribute__((aligned(16))) double mm_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const MmDims dm = mm_dims(mc);

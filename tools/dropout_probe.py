@@ -11,7 +11,7 @@ from safe_exploration_amd.ssm_cem.dropout_ssm_cem import McDropoutSSM
 
 
 class Conf:
-    mc_dropout_training_iterations, mc_dropout_num_samples, mc_dropout_predict_std, mc_dropout_reinitialize = 200, 30, False, False
+    mc_dropout_training_iterations, mc_dropout_num_samples, mc_dropout_predict_std, mc_dropout_reinitialize = int(os.environ.get("ITERS", 200)), 30, False, False
     mc_dropout_hidden_features = [int(v) for v in os.environ.get('HIDDEN', '64,64').split(',')]
     mc_dropout_type, mc_dropout_fixed_probability, mc_dropout_on_input, device = 'fixed', 0.1, False, 'cuda:0'
 

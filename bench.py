@@ -70,6 +70,29 @@ def mfma_per_launch_trmm(n_s, n_train, d_in, particles):
     return per_ptile * p128 * n_s
 
 
+def mlp_mfma_per_member(widths, d_in, n_s, with_jac):
+    """v_mfma_f64_16x16x4 instructions per ensemble member and 16-particle tile (csrc/sx_mlp_mfma.hpp; hidden layers padded
+    to row-blocks of 16 units): layer 1 (K = D + 1 with the bias column), the 64-wide layers K-pair by K-pair, the output
+    rows, and per output the reverse sweep + Jacobian rows.  SQ_INSTS_MFMA agrees (profiles/r02_pmc_mlp.json)."""
+    nrb = [(w + 15) // 16 for w in widths]
+    n = nrb[0] * (2 if d_in + 1 > 4 else 1)
+    if len(widths) == 2:
+        n += nrb[1] * 4 * nrb[0]
+    n += 4 * nrb[-1]
+    if with_jac:
+        per_output = 4 * nrb[0] + (nrb[0] * 4 * nrb[1] if len(widths) == 2 else 0)
+        n += n_s * per_output
+    return n
+
+
+def mlp_flops_per_particle_step(widths, d_in, n_s, n_out, members):
+    """algorithmic: 2 x multiply-adds of the forward pass and of one reverse sweep per output"""
+    w = [d_in] + list(widths)
+    fwd = sum(a * b for a, b in zip(w[:-1], w[1:])) + w[-1] * n_out
+    bwd = sum(a * b for a, b in zip(w[:-1], w[1:])) + w[-1]
+    return 2 * members * (fwd + n_s * bwd)
+
+
 def pmc_summary(cfg):
     """The committed rocprofv3 --pmc summary for this config (profiles/r02_pmc_cfg<N>.json), or None.  bench.py cannot
     collect PMC counters itself; the numbers are only reported for the workload they were collected on."""
@@ -114,11 +137,41 @@ def cpu_baseline(w, budget_s=12.0):
                       f'OpenMP over particles, float64), {dt:.1f} s'}
 
 
-def roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, cfg):
+def cpu_baseline_mlp(w, ssm, budget_s=10.0):
+    """--ssm mc_dropout: the numpy oracle of the ensemble (oracle.gp.DropoutEnsemble, vectorised over the particles, one
+    process; numpy's BLAS threads) rolled out on chunks of particles of the first CEM iteration."""
+    import numpy as np
+    from oracle import cem as ocem
+    from oracle.gp import DropoutEnsemble
+    from safe_exploration_amd import problems
+    spec, H = w.spec, w.horizon
+    layers, masks = ssm.ensemble()
+    model = DropoutEnsemble(layers, masks, spec.n_s, predict_std=False)
+    prob = problems.oracle_problem(spec, ocem)
+    rng = np.random.default_rng(1)
+    std = np.full((H, spec.n_u), float(np.ravel(w.init_std)[0]))
+    chunk, done, t0 = 256, 0, time.perf_counter()
+    while (time.perf_counter() - t0) < budget_s:
+        ocem.rollout(prob, model, w.x0[0], std[None] * rng.normal(size=(chunk, H, spec.n_u)))
+        done += chunk
+    dt = time.perf_counter() - t0
+    return {'value': done * H / dt, 'unit': 'particle-steps/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'{done} particle rollouts (H={H}) in chunks of {chunk}, numpy oracle of the ensemble '
+                      f'(oracle/gp.py DropoutEnsemble + oracle/cem.py), float64, {dt:.1f} s'}
+
+
+def roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, cfg, mlp=None):
     """The `roofline` object of the JSON line, for the kernel that took the largest share of the timed region."""
     dominant = max(kernels, key=lambda k: kernels[k][0])
     avg_s = kernels[dominant][0] / kernels[dominant][1] * 1e-3
-    if dominant == 'trmm_reduce_kernel':
+    if dominant == 'cem_rollout_mlp_kernel':
+        # (the profiler slot of both MC-dropout rollout kernels; --ssm mc_dropout runs the matrix-core one)
+        units = E * P * H
+        tiles = (E * P + 15) // 16
+        n_mfma = tiles * mlp['members'] * (mlp_mfma_per_member(mlp['hidden'], d_in, spec.n_s, False)
+                                           + (H - 1) * mlp_mfma_per_member(mlp['hidden'], d_in, spec.n_s, True))
+        dominant_name = 'cem_rollout_mlp_mfma_kernel'
+    elif dominant == 'trmm_reduce_kernel':
         units = E * P                                # particle-steps one launch processes (one step of all particles)
         n_mfma = mfma_per_launch_trmm(spec.n_s, n_train, d_in, E * P)
     else:
@@ -132,15 +185,19 @@ def roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, cfg):
     traffic = None
     if pmc and pmc.get('workload') == f'cfg{cfg} N_train={n_train} H={H} P={P} E={E}':
         traffic = pmc.get('hbm_traffic_bytes_per_launch', {}).get(dominant)
+    is_mlp = dominant == 'cem_rollout_mlp_kernel'
     return {'bound': 'mfma', 'achieved': executed, 'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': frac, 'kernel': dominant, 'avg_launch_us': avg_s * 1e6, 'launches_timed': kernels[dominant][1],
-            'flops': 'EXECUTED: v_mfma_f64_16x16x4 instructions per launch (analytic count of the triangular form, equal '
-                     'to SQ_INSTS_MFMA) x 2048',
+            'frac': frac, 'kernel': dominant_name if is_mlp else dominant,
+            'avg_launch_us': avg_s * 1e6, 'launches_timed': kernels[dominant][1],
+            'flops': 'EXECUTED: v_mfma_f64_16x16x4 instructions per launch x 2048; analytic count, equal to SQ_INSTS_MFMA ('
+                     + ('csrc/sx_mlp_mfma.hpp, profiles/r02_pmc_mlp.json)' if is_mlp else 'the triangular form)'),
             'mfma_instructions_per_launch': n_mfma,
             'algorithmic_tflops': algorithmic,
             'algorithmic_flops_per_launch': flops_unit * units,
-            'algorithmic_note': 'SURVEY 8d counts 2 N^2 per output for K* Kinv; the kernel evaluates ||L^-1 k*||^2 (N^2), so '
-                                'algorithmic_tflops may exceed the peak',
+            'algorithmic_note': ('forward pass + one reverse sweep per output, 2 flops per multiply-add; the executed count '
+                                 'also holds the zero padding of the 3-4 row output / Jacobian products to 16 rows' if is_mlp
+                                 else 'SURVEY 8d counts 2 N^2 per output for K* Kinv; the kernel evaluates ||L^-1 k*||^2 '
+                                      '(N^2), so algorithmic_tflops may exceed the peak'),
             'traffic': traffic,
             'traffic_unit': 'B/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950; '
                             'profiles/r02_pmc_cfg*.json)',
@@ -182,6 +239,9 @@ def main():
     ap.add_argument('--n-train', type=int, default=0)
     ap.add_argument('--iters', type=int, default=0, help='CEM iterations per solve (reference default 8)')
     ap.add_argument('--elites', type=int, default=0, help='0 = 10 %% of the per-GPU particle count')
+    ap.add_argument('--ssm', default='gp', choices=['gp', 'mc_dropout'],
+                    help='state-space model: the exact GP of the BASELINE configs, or (not a BASELINE config) the '
+                         'reference\'s default MC-dropout network, 64 x 64 hidden units, 30 members, on the same problem')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true', help='leave the per-launch HIP events off (no roofline object)')
     args = ap.parse_args()
@@ -231,6 +291,21 @@ def main():
     warmup = args.warmup if args.warmup is not None else warmup
     n_train, d_in = spec.X.shape[0], spec.n_s + spec.n_u
     ssm, env = problems.build(spec, dev)
+    mlp = None
+    if args.ssm == 'mc_dropout':
+        if w.cfg == 5:
+            raise SystemExit('--ssm mc_dropout: configs 1-4 (config 5 drives the GP solver through the episode runner)')
+        from safe_exploration_amd.ssm_cem.dropout_ssm_cem import McDropoutSSM
+        mlp = {'hidden': [64, 64], 'members': 30}
+
+        class DropConf:         # experiments/sacred_helper.py:96-106 (network and member count), a short training
+            mc_dropout_training_iterations, mc_dropout_num_samples, mc_dropout_predict_std = 500, mlp['members'], False
+            mc_dropout_reinitialize, mc_dropout_hidden_features, mc_dropout_type = False, mlp['hidden'], 'fixed'
+            mc_dropout_fixed_probability, mc_dropout_on_input, mc_dropout_lengthscale, device = 0.02, False, 1e-4, str(dev)
+
+        ssm = McDropoutSSM(DropConf(), spec.n_s, spec.n_u)
+        ssm.update_model(torch.tensor(spec.X, dtype=torch.float64, device=dev),
+                         torch.tensor(spec.Y, dtype=torch.float64, device=dev), replace_old=True)
     if w.sharded:
         # ONE problem, particles sharded over the GPUs; the elite count does not grow with the GPU count: every rank
         # contributes its local top-k rows, so the per-iteration all-reduce stays at G x k x (2 + H n_u) doubles
@@ -323,19 +398,24 @@ def main():
         else:
             episodes_total = E * (world if not w.sharded else 1)
             particle_steps = (P * world if w.sharded else P * episodes_total) * H * iters * steps
-            flops_unit = algorithmic_flops_per_particle_step(spec.n_s, n_train, d_in)
+            flops_unit = algorithmic_flops_per_particle_step(spec.n_s, n_train, d_in) if mlp is None else \
+                mlp_flops_per_particle_step(mlp['hidden'], d_in, spec.n_s, spec.n_s, mlp['members'])
             stride = 1 if w.cfg == 4 else 4      # every stride-th launch of a kernel is timed (start_timer)
             per_kernel = {k: {'avg_launch_us': ms / n * 1e3, 'launches_timed': n,
                               'share_of_step': min(1.0, ms * stride / (elapsed * 1e3))}
                           for k, (ms, n) in kernels.items()}
             roofline = None
             if kernels:
-                roofline = roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, w.cfg)
+                roofline = roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, w.cfg, mlp)
             out = {
                 'metric': 'cem_particle_step_evals_per_s', 'value': particle_steps / elapsed, 'unit': 'particle-steps/s',
                 'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-                'config': {'workload': f'{w.name}: n_s={spec.n_s} n_u={spec.n_u}, exact GP N_train={n_train}, CEM H={H}, '
+                'config': {'workload': f'{w.name}: n_s={spec.n_s} n_u={spec.n_u}, '
+                                       + (f'exact GP N_train={n_train}' if mlp is None else
+                                          f'MC-dropout ensemble {mlp["hidden"]} x {mlp["members"]} members (NOT a BASELINE '
+                                          f'config: the reference\'s other state-space model on the same problem)')
+                                       + f', CEM H={H}, '
                                        f'{P} particles/GPU' + (f' x {E} episodes/GPU' if not w.sharded else '')
                                        + f', {iters} CEM iterations/solve, {elites} elites; 1 step = 1 MPC solve'
                                        + (f' ({w.notes})' if w.notes else ''),
@@ -353,8 +433,8 @@ def main():
                 'kernels': per_kernel,
             }
             if world == 1 and not args.no_cpu_baseline:
-                out['cpu_baseline'] = cpu_baseline(w)
-                if w.cfg == 2:
+                out['cpu_baseline'] = cpu_baseline(w) if mlp is None else cpu_baseline_mlp(w, ssm)
+                if w.cfg == 2 and mlp is None:
                     out['cpu_baseline']['reference_measured_elsewhere'] = REFERENCE_CPU
             os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1:

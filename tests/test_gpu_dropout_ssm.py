@@ -203,3 +203,43 @@ def test_matrix_core_kernel_equals_lane_kernel_at_the_default_size(mlp_path):
     np.testing.assert_allclose(out['mfma']['sigma'], out['valu']['sigma'], rtol=1e-8, atol=1e-16)
     np.testing.assert_allclose(out['mfma']['obj_cost'], out['valu']['obj_cost'], rtol=1e-9, atol=1e-13)
     np.testing.assert_array_equal(out['mfma']['con_cost'], out['valu']['con_cost'])
+
+
+@pytest.mark.parametrize('n_s,hidden,kw', [(2, [64, 64], dict(mc_dropout_on_input=True)),
+                                         (4, [48], dict(mc_dropout_type='concrete', mc_dropout_predict_std=True,
+                                                        mc_dropout_on_input=True)),
+                                         (4, [64, 64], dict())])
+def test_tiles_straddling_episodes_and_initial_ellipsoids(mlp_path, n_s, hidden, kw):
+    """E = 3 episodes of 37 particles: 16-particle tiles of the matrix-core kernel hold particles of two episodes (own start
+    state, own sampling distribution per lane); q0 given, so step 0 already takes the ellipsoid branch with its Jacobian.
+    Both kernels against each other; the lane kernel is pinned to the oracle by the tests above."""
+    if mlp_path == 'valu':
+        pytest.skip('one comparison covers both')
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.cem_mpc import cem_rollout
+    from safe_exploration_amd.gp_reachability_pytorch import make_env
+    from safe_exploration_amd.ssm_cem.dropout_ssm_cem import McDropoutSSM
+    spec = problems.pendulum(n_train=50, seed=4, model_error=0.02) if n_s == 2 else problems.cartpole(n_train=50, seed=4)
+    ssm = McDropoutSSM(conf(mc_dropout_hidden_features=hidden, mc_dropout_num_samples=11, **kw), n_s, 1)
+    env = make_env(n_s, 1, a=spec.a, b=spec.b, k_fb=spec.k_fb, l_mu=spec.l_mu, l_sigma=spec.l_sigma, beta=spec.beta,
+                   h_mat=spec.h_mat, h_vec=spec.h_vec, u_min=spec.u_min, u_max=spec.u_max)
+    E, P, H = 3, 37, 4
+    rng = np.random.default_rng(8)
+    x0 = T(rng.normal(0, 0.02, size=(E, n_s)))
+    q0 = T(np.stack([np.eye(n_s) * 1e-4 * (e + 1) for e in range(E)]))
+    mean = T(rng.normal(0, 0.05, size=(E, H, 1)))
+    std = T(rng.uniform(0.05, 0.2, size=(E, H, 1)))
+    noise = T(rng.normal(size=(E, P, H, 1)))
+    out = {}
+    for path in ('mfma', 'valu'):
+        if path == 'valu':
+            os.environ['SX_MLP_PATH'] = 'valu'
+        r = cem_rollout(ssm, env, x0, H, mean=mean, std=std, noise=noise, q0=q0, want_traj=True, want_sigma=True)
+        out[path] = {k: r[k].cpu().numpy() for k in ('traj', 'sigma', 'obj_cost', 'con_cost', 'actions')}
+        out[path]['status'] = int(r['status'].item())
+    assert out['mfma']['status'] == out['valu']['status']
+    np.testing.assert_array_equal(out['mfma']['actions'], out['valu']['actions'])
+    np.testing.assert_allclose(out['mfma']['traj'], out['valu']['traj'], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(out['mfma']['sigma'], out['valu']['sigma'], rtol=1e-8, atol=1e-18)
+    np.testing.assert_allclose(out['mfma']['obj_cost'], out['valu']['obj_cost'], rtol=1e-9, atol=1e-13)
+    np.testing.assert_array_equal(out['mfma']['con_cost'], out['valu']['con_cost'])

@@ -154,15 +154,31 @@ def objective_spec(env) -> Optional[Tuple[int, np.ndarray, np.ndarray, np.ndarra
     probe = torch.zeros((1, n_s), dtype=torch.float64)
     if env.objective_cost_function(probe) is None:          # default: maximise the predicted variance
         return _lib.SX_OBJ_NEG_VARIANCE, zeros, zeros, zeros
-    if hasattr(env, '_current_objective') and n_s == 2:     # pendulum: |theta_target - theta|, environments.py:505-510
-        return _lib.SX_OBJ_AFFINE_ABS, np.array([0., 1.]), np.array([0., float(env._current_objective)]), zeros
-    # an affine hook (lunar lander: -height, lunarlander.py:111-113) is identified by probing it
-    base = float(env.objective_cost_function(probe)[0])
-    w = np.array([float(env.objective_cost_function(torch.eye(n_s, dtype=torch.float64)[i:i + 1])[0]) - base
-                  for i in range(n_s)])
-    test = torch.tensor(np.random.default_rng(0).normal(size=(8, n_s)))
-    if base == 0.0 and np.allclose(env.objective_cost_function(test).numpy(), test.numpy() @ w, rtol=1e-12, atol=1e-12):
-        return _lib.SX_OBJ_AFFINE_ABS, zeros, zeros, w
+    # Any hook of the separable form  sum_i w_i |t_i - p_i| + v . p  -- the pendulum's |theta_target - theta|
+    # (environments.py:505-510), the lunar lander's -height (lunarlander.py:111-113) -- is identified by probing the public
+    # hook alone: far from the kinks the cost along axis i is a line on either side, with slopes v_i -+ w_i that meet at t_i.
+    hook = lambda x: np.asarray(env.objective_cost_function(torch.as_tensor(x, dtype=torch.float64)), dtype=np.float64).reshape(-1)
+    w_abs, target, w_lin = np.zeros(n_s), np.zeros(n_s), np.zeros(n_s)
+    for i in range(n_s):
+        far = 1024.0
+        for _ in range(2):       # second pass: probes just outside the kink found by the first (rounding ~ far * 2^-53)
+            x = np.zeros((4, n_s))
+            x[:, i] = [-2 * far, -far, far, 2 * far]
+            c = hook(x)
+            s_lo, s_hi = (c[1] - c[0]) / far, (c[3] - c[2]) / far
+            w_abs[i], w_lin[i] = 0.5 * (s_hi - s_lo), 0.5 * (s_hi + s_lo)
+            if abs(w_abs[i]) <= 1e-12:
+                w_abs[i] = 0.0
+                break
+            # the two lines c_lo + s_lo x and c_hi + s_hi x cross at the kink
+            target[i] = ((c[1] + s_lo * far) - (c[2] - s_hi * far)) / (s_hi - s_lo)
+            far = float(2.0 ** np.ceil(np.log2(2.0 * abs(target[i]) + 2.0)))
+        if abs(w_lin[i]) < 1e-12 * max(1.0, abs(w_abs[i])):    # (rounding of the two slopes)
+            w_lin[i] = 0.0
+    test = np.random.default_rng(0).normal(size=(16, n_s))
+    want = (np.abs(target[None] - test) * w_abs[None]).sum(1) + test @ w_lin
+    if np.allclose(hook(test), want, rtol=1e-9, atol=1e-9):
+        return _lib.SX_OBJ_AFFINE_ABS, w_abs, target, w_lin
     return None
 
 

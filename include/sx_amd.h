@@ -265,11 +265,27 @@ int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, in
                    double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* sx_cem_rollout for every CEM iteration after the first: the sampling distribution is not handed in but REFIT from the
+ * previous iteration's elite rows inside the kernel's prologue -- mean and unbiased standard deviation (0 when k == 1) over
+ *   elite_rows dev [E x k x (2 + H*n_u)]  the [con, obj, actions...] rows sx_cem_rank_refit writes (any order),
+ * by every workgroup for itself (a wave per column, fixed summation order: the same numbers in every workgroup and on
+ * every GPU), while the kernel's other start-up loads travel.  actions = mean + std * noise as in sx_cem_rollout.
+ *   mean_out, std_out dev [E x H*n_u] | both NULL   the refit, for callers that want to see it
+ * Only for models on the single-launch path (sx_cem_rollout_workspace_bytes() == 0) with 2 H n_u <= 256 (1 + n_s);
+ * SX_ERR_UNSUPPORTED otherwise: use sx_cem_rank_refit's mean / std and sx_cem_rollout there.
+ * Replaces: the refit step of ConstrainedCemMpc.get_actions (as sx_cem_rank_refit's mean / std outputs do), moved off the
+ * ranking kernel's serial tail. */
+int sx_cem_rollout_elites(const sx_gp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
+                          const double* elite_rows, int k, const double* noise, double* actions, double* traj, double* sigma,
+                          double* obj_cost, double* con_cost, int32_t* status, double* mean_out, double* std_out, void* stream);
+
 /* Bytes of workspace sx_cem_rollout needs for this model and problem size: 0 = the fused single-launch path applies;
  * < 0 = bad arguments. */
 int64_t sx_cem_rollout_workspace_bytes(const sx_gp_model* model, int E, int P, int H);
 
-/* Ranking + elite refit for E problems, one workgroup each.
+/* Ranking + elite refit for E problems.  One or two problems of up to 8192 candidates are ranked by counting, spread over
+ * the whole chip (csrc/sx_rank_count.hpp: needs elite_rows whenever mean is wanted); anything else by one workgroup per
+ * problem (csrc/sx_rank.hpp).  The choice depends on (E, P) only.
  * Candidates c = 0..P-1 of problem e have con = con_cost[(e*P+c)*cost_stride], obj likewise, and an action row of
  * `row_len` doubles at actions + (e*P+c)*act_stride.  Order: lexicographic (con, obj, c); NaN sorts last.
  *   elite_idx  dev int32 [E x k]            elite indices: the best first, the others in a deterministic but unspecified order (may be NULL)

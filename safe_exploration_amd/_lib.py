@@ -85,6 +85,8 @@ SIGNATURES = {
                                      c_void_p]),
     'sx_cem_rollout': (c_int, [POINTER(SxGpModel), POINTER(SxEnv), c_int, c_int, c_int] + [c_void_p] * 12
                        + [c_int64, c_void_p]),
+    'sx_cem_rollout_elites': (c_int, [POINTER(SxGpModel), POINTER(SxEnv), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_int] + [c_void_p] * 10),
     'sx_cem_rollout_workspace_bytes': (c_int64, [POINTER(SxGpModel), c_int, c_int, c_int]),
     'sx_profile_enable': (c_int, [c_int]),
     'sx_profile_stride': (c_int, [c_int]),

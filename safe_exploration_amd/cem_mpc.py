@@ -34,10 +34,12 @@ class Rollouts:
 def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, actions: Optional[Tensor] = None,
                 mean: Optional[Tensor] = None, std: Optional[Tensor] = None, noise: Optional[Tensor] = None,
                 q0: Optional[Tensor] = None, want_traj: bool = False, want_sigma: bool = False,
-                status: Optional[Tensor] = None):
-    """Thin wrapper over sx_cem_rollout.
+                status: Optional[Tensor] = None, elite_rows: Optional[Tensor] = None, want_dist: bool = False):
+    """Thin wrapper over sx_cem_rollout / sx_cem_rollout_elites.
 
-    x0 [E x n_s]; either `actions` [E x P x H x n_u] (given) or (`mean`, `std` [E x H x n_u], `noise` [E x P x H x n_u]).
+    x0 [E x n_s]; either `actions` [E x P x H x n_u] (given), or (`mean`, `std` [E x H x n_u], `noise` [E x P x H x n_u]),
+    or (`elite_rows` [E x k x (2 + H n_u)], `noise`): the distribution is then refit from the previous iteration's elite
+    rows in the rollout kernel's prologue (`fused_refit_applies`); `want_dist` returns that refit as `mean` / `std`.
     Returns dict(actions, obj_cost [E x P], con_cost [E x P], traj | None, sigma | None, status int32[1]).
     """
     n_s, n_u = ssm.num_states, ssm.num_actions
@@ -74,6 +76,17 @@ def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, act
                                           _lib.ptr(con), _lib.ptr(status), _lib.stream_ptr(dev)), 'sx_cem_rollout_mlp')
         return dict(actions=actions, obj_cost=obj, con_cost=con, traj=traj, sigma=sigma, status=status)
     model = ssm.device_model
+    if elite_rows is not None:
+        k = elite_rows.size(1)
+        if noise is None or tuple(elite_rows.shape) != (E, k, 2 + horizon * n_u) or not elite_rows.is_contiguous():
+            raise ValueError(f'elite_rows must be a contiguous [{E} x k x {2 + horizon * n_u}] tensor and come with noise')
+        m_out = torch.empty((E, horizon, n_u), dtype=torch.float64, device=dev) if want_dist else None
+        s_out = torch.empty((E, horizon, n_u), dtype=torch.float64, device=dev) if want_dist else None
+        _lib.check(lib.sx_cem_rollout_elites(ctypes.byref(model), ctypes.byref(env), E, P, horizon, _lib.ptr(x0.contiguous()),
+                                             _lib.ptr(q0), _lib.ptr(elite_rows), k, _lib.ptr(noise), _lib.ptr(actions),
+                                             _lib.ptr(traj), _lib.ptr(sigma), _lib.ptr(obj), _lib.ptr(con), _lib.ptr(status),
+                                             _lib.ptr(m_out), _lib.ptr(s_out), _lib.stream_ptr(dev)), 'sx_cem_rollout_elites')
+        return dict(actions=actions, obj_cost=obj, con_cost=con, traj=traj, sigma=sigma, status=status, mean=m_out, std=s_out)
     ws_bytes = int(lib.sx_cem_rollout_workspace_bytes(ctypes.byref(model), E, P, horizon))
     if ws_bytes < 0:
         raise _lib.SxError('sx_cem_rollout_workspace_bytes: bad arguments')
@@ -83,6 +96,16 @@ def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, act
                                   _lib.ptr(traj), _lib.ptr(sigma), _lib.ptr(obj), _lib.ptr(con), _lib.ptr(status),
                                   _lib.ptr(workspace), ws_bytes, _lib.stream_ptr(dev)), 'sx_cem_rollout')
     return dict(actions=actions, obj_cost=obj, con_cost=con, traj=traj, sigma=sigma, status=status)
+
+
+def fused_refit_applies(ssm, episodes: int, particles: int, horizon: int) -> bool:
+    """May the elite refit move from the ranking kernel's tail into the next rollout's prologue (sx_cem_rollout_elites)?
+    Exact-GP models on the single-launch path whose H n_u means and standard deviations fit the prologue's scratch."""
+    if getattr(ssm, 'kernel_family', 'rbf') != 'rbf':
+        return False
+    if 2 * horizon * ssm.num_actions > 256 * (1 + ssm.num_states):
+        return False
+    return int(_lib.lib().sx_cem_rollout_workspace_bytes(ctypes.byref(ssm.device_model), episodes, particles, horizon)) == 0
 
 
 def cem_rollout_stepwise(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, actions: Tensor, *, status: Tensor, group=None,
@@ -320,6 +343,25 @@ class FusedCemMpc:
             x = x @ a.t() + u @ b.t() + mean
         return torch.stack(plan, dim=1)
 
+    def _constant(self, name: str, episodes: int, dev, make) -> Tensor:
+        """A read-only device tensor that depends on (name, episodes, device) only, built once."""
+        cache = self.__dict__.setdefault('_constants', {})
+        key = (name, episodes, str(dev))
+        if key not in cache:
+            cache[key] = make()
+        return cache[key]
+
+    def _fresh_status(self, dev) -> Tensor:
+        """A zeroed int32[1] status word: slices of a pool that is zeroed once per 256 solves (one fill launch instead of
+        256).  A slice is handed out once per pool generation; callers read it right after the solve."""
+        pool = getattr(self, '_status_pool', None)
+        if pool is None or self._status_next >= pool.numel() or pool.device != dev:
+            self._status_pool = pool = torch.zeros(256, dtype=torch.int32, device=dev)
+            self._status_next = 0
+        i = self._status_next
+        self._status_next += 1
+        return pool[i:i + 1]
+
     def sample_noise(self, episodes: int = 1) -> Tensor:
         return torch.randn((episodes, self._local_rollouts, self._horizon, self._ssm.num_actions), dtype=torch.float64,
                            device=self._device, generator=self._gen)
@@ -340,17 +382,19 @@ class FusedCemMpc:
         E = x0.size(0)
         dev = x0.device
         L = H * n_u
+        # (the constant start distribution and the zeroed status words are kept between solves: three small launches per
+        # solve otherwise, 2 % of a config-2 solve)
         if init_mean is not None:
             mean = init_mean.to(dev).reshape(E, H, n_u).clone()
         elif self._warm_start == 'safe_policy':
             mean = self.safe_policy_plan(x0).contiguous()
         else:
-            mean = torch.zeros((E, H, n_u), dtype=torch.float64, device=dev)
+            mean = self._constant('zero_mean', E, dev, lambda: torch.zeros((E, H, n_u), dtype=torch.float64, device=dev))
         if init_std is not None:
             std = init_std.to(dev).reshape(E, H, n_u).clone()
         else:
-            std = self._init_std.to(dev).expand(E, H, n_u).contiguous()   # (already there: no copy)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+            std = self._constant('init_std', E, dev, lambda: self._init_std.to(dev).expand(E, H, n_u).contiguous())
+        status = self._fresh_status(dev)
         history: List[Rollouts] = []
         out = None
         xch = None
@@ -360,6 +404,10 @@ class FusedCemMpc:
             noise = torch.randn((self._num_iterations, E, self._local_rollouts, H, n_u), dtype=torch.float64,
                                 device=self._device, generator=self._gen)
         self._last_noise, self._last_actions = noise, None
+        # From the second iteration on the refit happens in the rollout kernel's prologue, straight from the elite rows of
+        # the ranking before it (sx_cem_rollout_elites): the ranking launches then skip their refit tail.
+        in_prologue = (not stepwise) and fused_refit_applies(self._ssm, E, self._local_rollouts, H)
+        rows = None
         for it in range(self._num_iterations):
             eps = noise[it] if noise is not None else self.sample_noise(E)
             if noise is None:
@@ -374,6 +422,9 @@ class FusedCemMpc:
                                               objective_hook=self._objective_hook) for e in range(E)]
                 r = dict(actions=acts, traj=None, obj_cost=torch.stack([q['obj_cost'] for q in per_e]),
                          con_cost=torch.stack([q['con_cost'] for q in per_e]))
+            elif rows is not None:
+                r = cem_rollout(self._ssm, self._env, x0, H, elite_rows=rows, noise=eps.contiguous(),
+                                want_traj=self._record or self._objective_hook is not None, status=status)
             else:
                 r = cem_rollout(self._ssm, self._env, x0, H, mean=mean, std=std, noise=eps.contiguous(),
                                 want_traj=self._record or self._objective_hook is not None, status=status)
@@ -388,7 +439,8 @@ class FusedCemMpc:
                 ev[1].record(torch.cuda.current_stream(dev))
                 self.rollout_events.append(ev)
             if self._world == 1:
-                out = cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites)
+                out = cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites,
+                                         want_rows=True, want_refit=not in_prologue)
             else:
                 k = self._local_elites
                 if xch is None:
@@ -411,11 +463,15 @@ class FusedCemMpc:
                     status = words
                 flat = cand.reshape(-1)
                 out = cem_rank_refit(flat, flat[1:], flat[2:], self._num_elites, cost_stride=2 + L,
-                                     act_stride=2 + L, row_len=L, num_candidates=self._world * k, num_problems=E)
+                                     act_stride=2 + L, row_len=L, num_candidates=self._world * k, num_problems=E,
+                                     want_rows=True, want_refit=not in_prologue)
                 if self.exchange_events is not None:
                     xev[1].record(torch.cuda.current_stream(dev))
                     self.exchange_events.append(xev)
-            mean, std = out['mean'].view(E, H, n_u), out['std'].view(E, H, n_u)
+            if in_prologue:
+                rows = out['elite_rows']
+            else:
+                mean, std = out['mean'].view(E, H, n_u), out['std'].view(E, H, n_u)
             self._last_actions = r['actions']
             if self._record and r['traj'] is not None:
                 for e in range(E):

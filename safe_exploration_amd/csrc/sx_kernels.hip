@@ -1,6 +1,7 @@
 // libsxamd: launchers + C ABI (include/sx_amd.h) over the kernels in sx_*.hpp.  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include "sx_fit_blocked.hpp"
 #include "sx_rollout.hpp"
 #include "sx_rank.hpp"
+#include "sx_rank_count.hpp"
 #include "sx_feat.hpp"
 #include "sx_mlp.hpp"
 #include "sx_mlp_mfma.hpp"
@@ -588,8 +590,12 @@ template <int NS, int NU>
 static int launch_rollout(const sx_gp_model* m, const sx_env* env, const RolloutPtrs& rp, double* workspace,
                           int64_t workspace_bytes, hipStream_t stream) {
     const bool all_at_once = fused_fits(NS, NU, m->n_train, m->n_pad, rp.H);
-    if (!all_at_once && !(NS > 1 && fused_fits(NS, NU, m->n_train, m->n_pad, rp.H, 1)))
+    if (!all_at_once && !(NS > 1 && fused_fits(NS, NU, m->n_train, m->n_pad, rp.H, 1))) {
+        if (rp.elite_rows) return SX_ERR_UNSUPPORTED;   // the refit prologue belongs to the single-launch kernel
         return launch_rollout_big<NS, NU>(m, env, rp, workspace, workspace_bytes, stream);
+    }
+    // (the refit prologue keeps 2 H n_u doubles in the Kstar / mean-row buffers: at least 256 + 256 NS of them)
+    if (rp.elite_rows && 2 * rp.H * NU > 256 + 256 * NS) return SX_ERR_UNSUPPORTED;
     const int nw = kRolloutThreads / 64;
     auto gc = make_gp_const<NS, NU>(m, nw);
     ReachConst<NS, NU> rc;
@@ -1062,6 +1068,23 @@ int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, in
 #undef CALL
 }
 
+int sx_cem_rollout_elites(const sx_gp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,
+                          const double* elite_rows, int k, const double* noise, double* actions, double* traj, double* sigma,
+                          double* obj_cost, double* con_cost, int32_t* status, double* mean_out, double* std_out, void* stream) {
+    if (!model || !env || !x0 || !actions || !obj_cost || !con_cost || !status || !elite_rows || !noise) return SX_ERR_ARG;
+    if (E <= 0 || P <= 0 || H <= 0 || k <= 0 || (mean_out == nullptr) != (std_out == nullptr)) return SX_ERR_ARG;
+    if (model->n_s != env->n_s || model->n_u != env->n_u) return SX_ERR_ARG;
+    if (env->m <= 0 || env->m > SX_MAX_M) return SX_ERR_UNSUPPORTED;
+    sx::RolloutPtrs rp{x0, q0, nullptr, nullptr, noise, actions, traj, sigma, obj_cost, con_cost, status, E, P, H};
+    rp.elite_rows = elite_rows;
+    rp.elite_k = k;
+    rp.mean_out = mean_out;
+    rp.std_out = std_out;
+#define CALL(NS, NU) sx::launch_rollout<NS, NU>(model, env, rp, nullptr, 0, (hipStream_t)stream)
+    SX_DISPATCH(model->n_s, model->n_u, CALL);
+#undef CALL
+}
+
 static bool feat_model_ok(const sx_feat_model* m) {
     if (!m || m->n_s <= 0 || m->n_s > SX_MAX_NS || m->n_u <= 0 || m->n_u > SX_MAX_NU) return false;
     if (m->n_layers < 0 || m->n_layers > SX_FEAT_MAX_LAYERS || m->n_feat <= 0 || m->n_feat > SX_FEAT_MAX_WIDTH) return false;
@@ -1174,6 +1197,27 @@ int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, 
     sx::RankArgs ra{P,      k,          row_len,    con_cost, obj_cost, (long long)cost_stride,
                     actions, (long long)act_stride, elite_idx, elite_rows, mean,     std,
                     best,   best_ok};
+    // Which kernel: by shape only (every rank of a multi-GPU solve must take the same one: the elite order differs).
+    // Counting spreads one or two problems over the chip (E P / 16 workgroups, all keys in each one's LDS); many problems at
+    // once already fill it with the one-workgroup kernel (SX_RANK_PATH = count | select overrides, for A/B measurements).
+    const int tiles = (P + 15) / 16;
+    bool count = P <= sx::kCountMaxP && E <= sx::kCountMaxE && (elite_rows || !mean) && (long long)E * tiles <= sx::kCountMaxGrid;
+    {
+        static const char* const forced = std::getenv("SX_RANK_PATH");
+        if (forced && forced[0] == 's') count = false;
+        if (forced && forced[0] == 'c') count = P <= sx::kCountMaxP && E <= sx::kCountMaxE && (elite_rows || !mean);
+    }
+    if (count) {
+        const size_t lds = (size_t)((P + 127) & ~127) * sizeof(sx::CountKey);
+        if (int rc = sx::allow_lds(sx::cem_rank_count_kernel, lds)) return rc;
+        static std::atomic<unsigned int> seq{0};
+        unsigned int* tickets = nullptr;
+        if (hipGetSymbolAddress((void**)&tickets, HIP_SYMBOL(sx::g_rank_tickets)) != hipSuccess) return SX_ERR_LAUNCH;
+        tickets += (size_t)(seq.fetch_add(1) % sx::kCountTicketSlots) * sx::kCountMaxE;
+        sx::launch(SX_PROF_RANK, sx::cem_rank_count_kernel, dim3((unsigned)tiles, (unsigned)E), dim3(sx::kCountThreads), lds,
+                   (hipStream_t)stream, ra, tickets);
+        return sx::check_launch();
+    }
     if (P > sx::kRankThreads * sx::kRankSlots) return SX_ERR_UNSUPPORTED;
     const int slots = (P + sx::kRankThreads - 1) / sx::kRankThreads;
     if (slots <= 4)

@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "../../include/sx_amd.h"
+#include "sx_refit.hpp"
 #include "sx_rollout.hpp"  // stamp() in diagnostic builds
 
 namespace sx {
@@ -70,11 +71,11 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 
-// column totals of red[R][Lc] (row-major): 16 lanes per column and a row reduction when the columns fit (Lc <= 64),
-// else one thread per column; `store(c, total)` is called once per column
-template <class Store>
+// column totals of red[R][Lc] (row-major): 16 lanes per column and a row reduction when the columns fit
+// (16 Lc <= NT threads), else one thread per column; `store(c, total)` is called once per column
+template <int NT, class Store>
 __device__ __forceinline__ void column_totals(const double* red, int Lc, int R, int tid, Store&& store) {
-    if (Lc <= 64) {
+    if (16 * Lc <= NT) {
         const int c = tid >> 4, j = tid & 15;
         double t = 0.0;
         if (c < Lc)
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             }
             red[tid] = s;
             __syncthreads();
-            column_totals(red, Lc, R, tid, [&](int cc, double t) { col_mean[cc] = t / k; });
+            column_totals<kRankThreads>(red, Lc, R, tid, [&](int cc, double t) { col_mean[cc] = t / k; });
             __syncthreads();
             const double mu = col_mean[c];
             double ss = 0.0;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(kRankThreads) void cem_rank_kernel(RankArgs ra) {
             }
             red[tid] = ss;  // (the column owners finished reading red before the barrier above)
             __syncthreads();
-            column_totals(red, Lc, R, tid, [&](int cc, double t) {
+            column_totals<kRankThreads>(red, Lc, R, tid, [&](int cc, double t) {
                 ra.mean[(long long)e * L + c0 + cc] = col_mean[cc];
                 if (ra.std) ra.std[(long long)e * L + c0 + cc] = (k > 1) ? sqrt(t / (k - 1)) : 0.0;
             });

@@ -5,6 +5,7 @@
 #include "../../include/sx_amd.h"
 #include "sx_gp.hpp"
 #include "sx_reach.hpp"
+#include "sx_refit.hpp"
 
 namespace sx {
 
@@ -41,6 +42,12 @@ struct RolloutPtrs {
     double* con_cost;
     int* status;
     int E, P, H;
+    // sx_cem_rollout_elites: the sampling distribution is refit from the previous iteration's elite rows
+    // [E x elite_k x (2 + H n_u)] in the kernel's prologue (mean / std above are then unused)
+    const double* elite_rows = nullptr;
+    int elite_k = 0;
+    double* mean_out = nullptr;   // [E x H n_u] the refit, written by the first workgroup of each problem (may be null)
+    double* std_out = nullptr;
 };
 
 // BYOUT = false: Kstar of all outputs in LDS at once -- two barriers per step (the kernel measured throughout DESIGN.md).
@@ -72,6 +79,45 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
     const MfmaHead head = gp_mfma_head(gc, stage_tab, wave, nw, lane, gc.stage_cap);
     const int4* __restrict__ const tab_one = stage_tab + (size_t)nw * (1 + gc.stage_cap);
     gp_load_xs(gc, lds);
+    // The sampling distribution.  Either given (mean, std), or refit here from the elite rows the ranking kernel left behind
+    // (sx_cem_rollout_elites): every workgroup computes the same H n_u means and standard deviations for itself, a wave per
+    // group of columns and no barrier inside (wave_refit_columns), while the loads above are still travelling -- the refit used to be
+    // the serial tail of the ranking kernel, ~5 us per CEM iteration on one compute unit.  The result sits in the (still
+    // unused) Kstar buffer until the actions are sampled.
+    const double* dist_mean = rp.mean + (int64_t)e * H * NU;
+    const double* dist_std = rp.std + (int64_t)e * H * NU;
+    // (the first trip's noise draw / given action is requested before the refit, so that it travels meanwhile)
+    double first_in = 0.0;
+    if (tid < SX_TILE * H * NU && c0 + tid / (H * NU) < rp.P) {
+        const int64_t gi = ((int64_t)e * rp.P + c0) * (H * NU) + tid;
+        first_in = rp.noise ? rp.noise[gi] : rp.actions[gi];
+    }
+    if (rp.elite_rows) {
+        const int L = H * NU, W = 2 + L;
+        double* const ms = lds.kfrag;   // [2][L]
+        const double* rows = rp.elite_rows + (int64_t)e * rp.elite_k * W + 2;
+        const bool publish = (blockIdx.x - e * tiles_per_problem) == 0 && rp.mean_out;
+        // 2^cshift adjacent columns per wave and trip: all columns in one trip when they fit (L <= 64 nw)
+        int cshift = 0;
+        while ((nw << cshift) < L && cshift < 6) ++cshift;
+        const int cc = lane & ((1 << cshift) - 1);
+        for (int c0 = wave << cshift; c0 < L; c0 += nw << cshift) {
+            const int col = c0 + cc;
+            double m, sd;
+            wave_refit_columns(rows + (col < L ? col : L - 1), rp.elite_k, W, lane, cshift, m, sd);
+            if ((lane >> cshift) == 0 && col < L) {
+                ms[col] = m;
+                ms[L + col] = sd;
+                if (publish) {
+                    rp.mean_out[(int64_t)e * L + col] = m;
+                    rp.std_out[(int64_t)e * L + col] = sd;
+                }
+            }
+        }
+        __syncthreads();
+        dist_mean = ms;
+        dist_std = ms + L;
+    }
     // sample (or load) this tile's action sequences: a = mean + std * eps
     for (int i = tid; i < SX_TILE * H * NU; i += blockDim.x) {
         const int c = i / (H * NU);
@@ -80,10 +126,10 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
         if (c0 + c < rp.P) {
             const int64_t gi = ((int64_t)e * rp.P + c0 + c) * (H * NU) + r;
             if (rp.noise) {
-                a = rp.mean[(int64_t)e * H * NU + r] + rp.std[(int64_t)e * H * NU + r] * rp.noise[gi];
+                a = dist_mean[r] + dist_std[r] * (i == tid ? first_in : rp.noise[gi]);
                 rp.actions[gi] = a;
             } else {
-                a = rp.actions[gi];
+                a = (i == tid) ? first_in : rp.actions[gi];
             }
         }
         acts[i] = a;

@@ -208,6 +208,70 @@ def test_rank_refit_vs_oracle(P, k, L):
         np.testing.assert_array_equal(rows[:, 2:], act[e][idx])
 
 
+@pytest.mark.parametrize('E,P,k,L', [(1, 2048, 2048, 3), (2, 130, 7, 300), (1, 17, 17, 33), (1, 8192, 819, 30), (1, 8191, 1, 5),
+                                     (2, 4100, 2048, 9)])
+def test_rank_by_counting_edge_shapes(E, P, k, L):
+    """The multi-workgroup counting kernel (csrc/sx_rank_count.hpp) at its edges: every candidate an elite, rows wider than
+    32 / 256 columns, a ragged last tile, the largest candidate count it takes, k = 1, all keys tied (ties go to the lower
+    index), NaN costs last -- elite rows come out in rank order."""
+    from safe_exploration_amd.cem_mpc import cem_rank_refit
+    rng = np.random.default_rng(P + k + L)
+    con = rng.choice([0., 0., 3., 10., 13., 20.], size=(E, P))
+    obj = rng.normal(size=(E, P))
+    obj[:, ::5] = obj[:, 1:2]                     # many exact ties
+    if E > 1:
+        con[1], obj[1] = 3.0, 0.25                # problem 1: every key the same
+    obj[0, 3] = np.nan
+    con[0, min(9, P - 1)] = np.nan
+    act = rng.normal(size=(E, P, L))
+    out = cem_rank_refit(T(con), T(obj), T(act), k, want_rows=True)
+    for e in range(E):
+        idx = ocem.rank(con[e], obj[e], k)
+        got = out['elite_idx'][e].cpu().numpy()
+        if np.isnan(con[e]).any() and k == P:
+            # (the oracle ties a NaN constraint cost with +inf; the kernels rank NaN behind everything: same set)
+            np.testing.assert_array_equal(np.sort(got), np.sort(idx))
+        else:
+            np.testing.assert_array_equal(got, idx)                     # rank order, ties by index
+        rows = out['elite_rows'][e].cpu().numpy()
+        np.testing.assert_array_equal(rows[:, 0], con[e][got])
+        np.testing.assert_array_equal(rows[:, 1], obj[e][got])
+        np.testing.assert_array_equal(rows[:, 2:], act[e][got])
+        m, sd = ocem.refit(act[e][got])
+        np.testing.assert_allclose(out['mean'][e].cpu().numpy(), m, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(out['std'][e].cpu().numpy(), sd, rtol=1e-12, atol=1e-14)
+        np.testing.assert_array_equal(out['best'][e].cpu().numpy(), act[e][got[0]])
+        assert int(out['best_ok'][e]) == int(con[e][got[0]] == 0)
+    # without the refit (the multi-GPU local stage, and every ranking whose refit moved into the next rollout's prologue)
+    out2 = cem_rank_refit(T(con), T(obj), T(act), k, want_rows=True, want_refit=False)
+    np.testing.assert_array_equal(out2['elite_rows'].cpu().numpy(), out['elite_rows'].cpu().numpy())
+
+
+@pytest.mark.parametrize('E,P,H,k', [(1, 100, 7, 13), (3, 64, 15, 64), (1, 40, 5, 1), (2, 33, 12, 700)])
+def test_rollout_refits_from_elite_rows(E, P, H, k):
+    """sx_cem_rollout_elites: the sampling distribution refit from elite rows in the rollout kernel's prologue equals the
+    oracle's refit (mean / unbiased std over the rows), the sampled actions are mean + std * noise, and costs / status equal
+    those of sx_cem_rollout handed the same distribution."""
+    from safe_exploration_amd.cem_mpc import cem_rollout, fused_refit_applies
+    ssm, gp, env, prob = pendulum_problem()
+    assert fused_refit_applies(ssm, E, P, H)
+    rng = np.random.default_rng(E + P + H + k)
+    x0 = rng.normal(0, 0.05, size=(E, 2))
+    noise = rng.normal(size=(E, P, H, 1))
+    rows = np.concatenate([rng.choice([0., 3.], size=(E, k, 1)), rng.normal(size=(E, k, 1)),
+                           rng.normal(0.1, 0.3, size=(E, k, H))], axis=2)
+    r = cem_rollout(ssm, env, T(x0), H, elite_rows=T(rows), noise=T(noise), want_dist=True)
+    for e in range(E):
+        m, sd = ocem.refit(rows[e, :, 2:].reshape(k, H, 1))
+        np.testing.assert_allclose(r['mean'][e].cpu().numpy(), m, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(r['std'][e].cpu().numpy(), sd, rtol=1e-12, atol=1e-15)
+    r2 = cem_rollout(ssm, env, T(x0), H, mean=r['mean'], std=r['std'], noise=T(noise))
+    torch.testing.assert_close(r['actions'], r2['actions'], rtol=0, atol=0)
+    torch.testing.assert_close(r['obj_cost'], r2['obj_cost'], rtol=0, atol=0)
+    torch.testing.assert_close(r['con_cost'], r2['con_cost'], rtol=0, atol=0)
+    assert int(r['status'].item()) == int(r2['status'].item())
+
+
 def test_full_solve_vs_oracle():
     """Whole get_actions loop with injected noise: elites, refits and the selected actions match the oracle."""
     from safe_exploration_amd.cem_mpc import FusedCemMpc

@@ -505,7 +505,11 @@ def test_config3_and_config5_shapes():
     best, ok, _, status = mpc.solve(x0s, noise=noise)
     for e in (0, 5):
         b1, ok1, _, _ = mpc.solve(x0s[e:e + 1].contiguous(), noise=noise[:, e:e + 1].contiguous())
-        assert torch.equal(b1[0], best[e]) and int(ok1[0]) == int(ok[e])
+        # (8 problems at once are ranked by one workgroup each, a single one by counting over the whole chip: the same
+        # elite SET in a different row order, so the refit sums in a different order -- last-bit differences, where the
+        # small-shape tests, which take one kernel for both, stay bit-identical)
+        torch.testing.assert_close(b1[0], best[e], rtol=0, atol=1e-12)
+        assert int(ok1[0]) == int(ok[e])
     assert int(status.item()) == 0
 
 

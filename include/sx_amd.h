@@ -283,6 +283,12 @@ int sx_cem_rollout_elites(const sx_gp_model* model, const sx_env* env, int E, in
  * < 0 = bad arguments. */
 int64_t sx_cem_rollout_workspace_bytes(const sx_gp_model* model, int E, int P, int H);
 
+/* 1 if sx_cem_rank_refit ranks E problems of P candidates by counting over the whole chip (elite rows in rank order), 0 if
+ * by one workgroup per problem (best first, then index order).  Depends on (E, P) only.  A caller that moves the refit into
+ * the next rollout (sx_cem_rollout_elites) does so where this returns 1: with many problems at once the one-workgroup
+ * kernels refit side by side and the rollout's prologue has nothing to gain. */
+int sx_cem_rank_counts(int E, int P);
+
 /* Ranking + elite refit for E problems.  One or two problems of up to 8192 candidates are ranked by counting, spread over
  * the whole chip (csrc/sx_rank_count.hpp: needs elite_rows whenever mean is wanted); anything else by one workgroup per
  * problem (csrc/sx_rank.hpp).  The choice depends on (E, P) only.

@@ -98,14 +98,20 @@ def cem_rollout(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, horizon: int, *, act
     return dict(actions=actions, obj_cost=obj, con_cost=con, traj=traj, sigma=sigma, status=status)
 
 
-def fused_refit_applies(ssm, episodes: int, particles: int, horizon: int) -> bool:
+def fused_refit_applies(ssm, episodes: int, particles: int, horizon: int, candidates: Optional[int] = None) -> bool:
     """May the elite refit move from the ranking kernel's tail into the next rollout's prologue (sx_cem_rollout_elites)?
-    Exact-GP models on the single-launch path whose H n_u means and standard deviations fit the prologue's scratch."""
+    Exact-GP models on the single-launch path whose H n_u means and standard deviations fit the prologue's scratch, where
+    the ranking that produces the rows (over `candidates` rows per problem; default: the particles) is the counting one."""
     if getattr(ssm, 'kernel_family', 'rbf') != 'rbf':
         return False
     if 2 * horizon * ssm.num_actions > 256 * (1 + ssm.num_states):
         return False
-    return int(_lib.lib().sx_cem_rollout_workspace_bytes(ctypes.byref(ssm.device_model), episodes, particles, horizon)) == 0
+    lib = _lib.lib()
+    if int(lib.sx_cem_rollout_workspace_bytes(ctypes.byref(ssm.device_model), episodes, particles, horizon)) != 0:
+        return False
+    # worth it where the ranking spreads over the chip and its refit would be a serial tail; many problems at once
+    # (config 5: 8 episodes per GPU) rank and refit side by side, one workgroup each
+    return int(lib.sx_cem_rank_counts(episodes, particles if candidates is None else candidates)) == 1
 
 
 def cem_rollout_stepwise(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, actions: Tensor, *, status: Tensor, group=None,
@@ -406,7 +412,10 @@ class FusedCemMpc:
         self._last_noise, self._last_actions = noise, None
         # From the second iteration on the refit happens in the rollout kernel's prologue, straight from the elite rows of
         # the ranking before it (sx_cem_rollout_elites): the ranking launches then skip their refit tail.
-        in_prologue = (not stepwise) and fused_refit_applies(self._ssm, E, self._local_rollouts, H)
+        chunks = rank_chunks(self._local_rollouts)
+        final_candidates = (self._world * self._local_elites if self._world > 1
+                            else chunks * self._num_elites if chunks > 1 else self._local_rollouts)
+        in_prologue = (not stepwise) and fused_refit_applies(self._ssm, E, self._local_rollouts, H, final_candidates)
         rows = None
         for it in range(self._num_iterations):
             eps = noise[it] if noise is not None else self.sample_noise(E)
@@ -440,7 +449,7 @@ class FusedCemMpc:
                 self.rollout_events.append(ev)
             if self._world == 1:
                 out = cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites,
-                                         want_rows=True, want_refit=not in_prologue)
+                                         want_rows=in_prologue, want_refit=not in_prologue)
             else:
                 k = self._local_elites
                 if xch is None:
@@ -464,7 +473,7 @@ class FusedCemMpc:
                 flat = cand.reshape(-1)
                 out = cem_rank_refit(flat, flat[1:], flat[2:], self._num_elites, cost_stride=2 + L,
                                      act_stride=2 + L, row_len=L, num_candidates=self._world * k, num_problems=E,
-                                     want_rows=True, want_refit=not in_prologue)
+                                     want_rows=in_prologue, want_refit=not in_prologue)
                 if self.exchange_events is not None:
                     xev[1].record(torch.cuda.current_stream(dev))
                     self.exchange_events.append(xev)

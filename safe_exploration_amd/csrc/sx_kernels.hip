@@ -1188,6 +1188,17 @@ int sx_cem_rollout_mlp(const sx_mlp_model* model, const sx_env* env, int E, int 
 #undef CALL
 }
 
+// Which ranking kernel: by shape only (every rank of a multi-GPU solve must take the same one: the elite order differs).
+// Counting spreads one or two problems over the chip (E P / 16 workgroups, all keys in each one's LDS); many problems at
+// once already fill it with the one-workgroup kernel (SX_RANK_PATH = count | select overrides, for A/B measurements).
+int sx_cem_rank_counts(int E, int P) {
+    if (E <= 0 || P <= 0 || P > sx::kCountMaxP || E > sx::kCountMaxE) return 0;
+    static const char* const forced = std::getenv("SX_RANK_PATH");
+    if (forced && forced[0] == 's') return 0;
+    if (forced && forced[0] == 'c') return 1;
+    return (long long)E * ((P + 15) / 16) <= sx::kCountMaxGrid ? 1 : 0;
+}
+
 int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, const double* obj_cost,
                       int64_t cost_stride, const double* actions, int64_t act_stride, int32_t* elite_idx,
                       double* elite_rows, double* mean, double* std, double* best, int32_t* best_ok, void* stream) {
@@ -1197,16 +1208,8 @@ int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, 
     sx::RankArgs ra{P,      k,          row_len,    con_cost, obj_cost, (long long)cost_stride,
                     actions, (long long)act_stride, elite_idx, elite_rows, mean,     std,
                     best,   best_ok};
-    // Which kernel: by shape only (every rank of a multi-GPU solve must take the same one: the elite order differs).
-    // Counting spreads one or two problems over the chip (E P / 16 workgroups, all keys in each one's LDS); many problems at
-    // once already fill it with the one-workgroup kernel (SX_RANK_PATH = count | select overrides, for A/B measurements).
+    const bool count = sx_cem_rank_counts(E, P) != 0 && (elite_rows || !mean);
     const int tiles = (P + 15) / 16;
-    bool count = P <= sx::kCountMaxP && E <= sx::kCountMaxE && (elite_rows || !mean) && (long long)E * tiles <= sx::kCountMaxGrid;
-    {
-        static const char* const forced = std::getenv("SX_RANK_PATH");
-        if (forced && forced[0] == 's') count = false;
-        if (forced && forced[0] == 'c') count = P <= sx::kCountMaxP && E <= sx::kCountMaxE && (elite_rows || !mean);
-    }
     if (count) {
         const size_t lds = (size_t)((P + 127) & ~127) * sizeof(sx::CountKey);
         if (int rc = sx::allow_lds(sx::cem_rank_count_kernel, lds)) return rc;

@@ -97,7 +97,11 @@ __global__ __launch_bounds__(kRolloutThreads) void cem_rollout_kernel(GpConst<NS
         double* const ms = lds.kfrag;   // [2][L]
         const double* rows = rp.elite_rows + (int64_t)e * rp.elite_k * W + 2;
         const bool publish = (blockIdx.x - e * tiles_per_problem) == 0 && rp.mean_out;
-        // 2^cshift adjacent columns per wave and trip: all columns in one trip when they fit (L <= 64 nw)
+        // 2^cshift adjacent columns per wave and trip: all columns in one trip when they fit (L <= 64 nw).
+        // (This code runs once per launch, but its registers are part of the whole kernel's allocation problem, and the step
+        // loop's spills depend on its spelling.  A/B on one box, config 2 / config 5 launch: 8 loads in flight per lane
+        // 129.9 / 974 us, 16 with the uniform guards 135.6 / 1030, 16 without 130.7 / 990, as a non-inlined function
+        // 147.7 / 1116 -- config 5 does not even execute it.)
         int cshift = 0;
         while ((nw << cshift) < L && cshift < 6) ++cshift;
         const int cc = lane & ((1 << cshift) - 1);

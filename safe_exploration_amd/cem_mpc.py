@@ -292,9 +292,9 @@ class FusedCemMpc:
         self._local_elites = num_elites     # the same k on every rank
         if num_elites > RANK_MAX_ELITES:
             raise ValueError(f'num_elites={num_elites} exceeds the ranking kernel\'s limit of {RANK_MAX_ELITES}')
-        if self._world > 1 and self._world * num_elites > RANK_MAX_CANDIDATES:
-            raise ValueError(f'{self._world * num_elites} candidates after the exchange exceed the ranking kernel\'s limit '
-                             f'of {RANK_MAX_CANDIDATES}')
+        if self._world > 1 and self._world * (num_elites + 1) > RANK_MAX_CANDIDATES:
+            raise ValueError(f'{self._world * (num_elites + 1)} candidate rows after the exchange exceed the ranking kernel\'s '
+                             f'limit of {RANK_MAX_CANDIDATES}')
         chunks = rank_chunks(self._local_rollouts)     # > 1: two-level ranking on this GPU (cem_rank_refit_any)
         if chunks > 1 and (num_elites > self._local_rollouts // chunks or chunks * num_elites > RANK_MAX_CANDIDATES):
             raise ValueError(f'{self._local_rollouts} particles per GPU rank in {chunks} chunks: num_elites={num_elites} is '
@@ -413,7 +413,7 @@ class FusedCemMpc:
         # From the second iteration on the refit happens in the rollout kernel's prologue, straight from the elite rows of
         # the ranking before it (sx_cem_rollout_elites): the ranking launches then skip their refit tail.
         chunks = rank_chunks(self._local_rollouts)
-        final_candidates = (self._world * self._local_elites if self._world > 1
+        final_candidates = (self._world * (self._local_elites + (1 if E == 1 else 0)) if self._world > 1
                             else chunks * self._num_elites if chunks > 1 else self._local_rollouts)
         in_prologue = (not stepwise) and fused_refit_applies(self._ssm, E, self._local_rollouts, H, final_candidates)
         rows = None
@@ -472,7 +472,7 @@ class FusedCemMpc:
                     status = words
                 flat = cand.reshape(-1)
                 out = cem_rank_refit(flat, flat[1:], flat[2:], self._num_elites, cost_stride=2 + L,
-                                     act_stride=2 + L, row_len=L, num_candidates=self._world * k, num_problems=E,
+                                     act_stride=2 + L, row_len=L, num_candidates=xch.candidates, num_problems=E,
                                      want_rows=in_prologue, want_refit=not in_prologue)
                 if self.exchange_events is not None:
                     xev[1].record(torch.cuda.current_stream(dev))

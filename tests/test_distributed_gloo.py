@@ -1,7 +1,8 @@
 """CPU, 2 processes, gloo: the N > 1 data path of the solver.  `distributed.EliteExchange` is the code
-`FusedCemMpc.solve` runs between its local and its global ranking launch (particle sharding, zero-padded slots, ONE
-all-reduce per iteration, status words riding along with the last one); here the two launches around it are played by
-the oracle's ranking, so the whole exchange runs without a GPU."""
+`FusedCemMpc.solve` runs between its local and its global ranking launch (particle sharding, ONE collective per
+iteration -- an all-gather of the ranks' elite blocks for one problem, an all-reduce over zero-padded slots for several --
+status words riding along with the last one); here the two launches around it are played by the oracle's ranking, so
+the whole exchange runs without a GPU."""
 import os
 import socket
 
@@ -28,7 +29,9 @@ def _worker(rank, port, P, k, L, E, iters, out):
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
         xch = distributed.EliteExchange(iters, E, k, L, dist.group.WORLD, 'cpu')
-        assert (xch.world, xch.rank) == (WORLD, rank) and tuple(xch.slots(0).shape) == (E, WORLD, k, 2 + L)
+        nrows = k + 1 if E == 1 else k              # one problem: a padding / status row behind every rank's k rows
+        assert (xch.world, xch.rank, xch.rows) == (WORLD, rank, nrows)
+        assert tuple(xch.slots(0).shape) == (E, WORLD, nrows, 2 + L) and xch.candidates == WORLD * nrows
         count, off = distributed.shard_particles(P, WORLD, rank)   # uneven when P is odd: the first rank takes one more
         digest = b''
         for it in range(iters):
@@ -44,9 +47,10 @@ def _worker(rank, port, P, k, L, E, iters, out):
             status = torch.tensor([4 if rank == 1 else 0], dtype=torch.int32)
             before = xch.local_slot(it).clone()
             cand, words = xch.exchange(it, status if last else None)
-            assert cand.data_ptr() == xch.buf[it].data_ptr()                       # in place, no copy
-            assert tuple(cand.shape) == (E, WORLD * k, 2 + L)
-            np.testing.assert_array_equal(xch.local_slot(it).numpy(), before.numpy())   # own slot untouched by the sum
+            assert cand.data_ptr() == xch.buf[it].data_ptr()                       # the collective's own buffer, no copy
+            assert tuple(cand.shape) == (E, WORLD * nrows, 2 + L)
+            np.testing.assert_array_equal(xch.local_slot(it).numpy(), before.numpy())   # own slot untouched
+            np.testing.assert_array_equal(xch.slots(it)[:, rank, :k].numpy(), before.numpy())   # and where it belongs
             if last:
                 assert words.dtype == torch.int32 and words.tolist() == [0, 4]     # every rank sees every rank's word
             else:
@@ -54,7 +58,8 @@ def _worker(rank, port, P, k, L, E, iters, out):
             for e in range(E):
                 c = cand[e].numpy()
                 # global selection from the G k candidates == selection from the whole population
-                sel = ocem.rank(c[:, 0], c[:, 1], k)
+                sel = ocem.rank(c[:, 0], c[:, 1], k)       # (padding rows are [NaN, NaN, ...]: ranked last)
+                assert not np.isnan(c[sel][:, :2]).any()
                 want = ocem.rank(con[e], obj[e], k)
                 np.testing.assert_array_equal(c[sel][:, 2:], act[e, want])
                 mean, std = ocem.refit(c[sel][:, 2:].reshape(k, L, 1))

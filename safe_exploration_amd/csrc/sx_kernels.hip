@@ -1213,10 +1213,24 @@ int sx_cem_rank_refit(int E, int P, int k, int row_len, const double* con_cost, 
     if (count) {
         const size_t lds = (size_t)((P + 127) & ~127) * sizeof(sx::CountKey);
         if (int rc = sx::allow_lds(sx::cem_rank_count_kernel, lds)) return rc;
+        // the refit's ticket cells: one set per launch, kCountTicketSlots sets in rotation (launches whose refits overlap in
+        // time must be fewer than that); the symbol's address is looked up once per device
         static std::atomic<unsigned int> seq{0};
         unsigned int* tickets = nullptr;
-        if (hipGetSymbolAddress((void**)&tickets, HIP_SYMBOL(sx::g_rank_tickets)) != hipSuccess) return SX_ERR_LAUNCH;
-        tickets += (size_t)(seq.fetch_add(1) % sx::kCountTicketSlots) * sx::kCountMaxE;
+        if (mean) {
+            static std::mutex mu;
+            static std::map<int, unsigned int*> base;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> lock(mu);
+            auto it = base.find(dev);
+            if (it == base.end()) {
+                unsigned int* p = nullptr;
+                if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(sx::g_rank_tickets)) != hipSuccess) return SX_ERR_LAUNCH;
+                it = base.emplace(dev, p).first;
+            }
+            tickets = it->second + (size_t)(seq.fetch_add(1) % sx::kCountTicketSlots) * sx::kCountMaxE;
+        }
         sx::launch(SX_PROF_RANK, sx::cem_rank_count_kernel, dim3((unsigned)tiles, (unsigned)E), dim3(sx::kCountThreads), lds,
                    (hipStream_t)stream, ra, tickets);
         return sx::check_launch();

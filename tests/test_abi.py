@@ -105,3 +105,16 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith('.py'):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+
+
+def test_rank_kernel_choice_depends_on_the_shape_only():
+    """sx_cem_rank_counts (host code, no GPU): one or two problems of up to 8192 candidates are ranked by counting over the
+    whole chip, anything else by one workgroup per problem -- the rule every rank of a multi-GPU solve must agree on."""
+    from safe_exploration_amd import _lib
+    lib = _lib.lib()
+    if os.environ.get('SX_RANK_PATH'):
+        pytest.skip('SX_RANK_PATH forces a kernel')
+    want = {(1, 64): 1, (1, 4096): 1, (2, 4096): 1, (3, 4096): 1, (4, 4096): 0, (8, 4096): 0, (1, 8192): 1, (1, 8193): 0,
+            (1, 16384): 0, (64, 16): 1, (65, 16): 0, (0, 16): 0, (1, 0): 0, (1, 3281): 1}
+    for (E, P), w in want.items():
+        assert int(lib.sx_cem_rank_counts(E, P)) == w, (E, P)

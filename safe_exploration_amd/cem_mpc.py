@@ -504,12 +504,25 @@ class FusedCemMpc:
                     history.append(Rollouts(r['traj'][e], r['actions'][e], r['obj_cost'][e], r['con_cost'][e]))
         return out['best'].view(E, H, n_u), out['best_ok'], history, status
 
-    def _solve_checked(self, x0: Tensor, where: str):
-        """`solve` + the one device->host hand-off of a solve (status words + feasibility flags) + the reference's
-        failure behaviour.  Returns (best [E x H x n_u], found bool [E] on the host, rollouts)."""
+    def _solve_checked(self, x0: Tensor, where: str, q_block: Optional[Tensor] = None):
+        """`solve` + the ONE device->host hand-off of a solve + the reference's failure behaviour.  The hand-off carries the
+        status words, the feasibility flags, the selected actions and "is any entry of `q_block` non-zero" (the callers'
+        point-state check, evaluated on the device and read here instead of in a synchronisation of its own before the
+        solve).  Returns (best [E x H x n_u] ON THE HOST, found bool [E] on the host, rollouts)."""
+        nonpoint = ((q_block != 0).any().reshape(1).to(torch.float64) if q_block is not None
+                    else torch.zeros(1, dtype=torch.float64, device=x0.device))
+
+        def hand_off(best, best_ok, status):
+            G, E = status.numel(), best_ok.numel()
+            packed = torch.cat((status.to(torch.float64), best_ok.to(torch.float64), nonpoint, best.reshape(-1))).cpu()
+            return (packed[:G].to(torch.int64), packed[G:G + E] != 0, bool(packed[G + E] != 0),
+                    packed[G + E + 1:].view(best.shape))
+
         best, best_ok, history, status = self.solve(x0)
-        flags = torch.cat((status, best_ok)).cpu()
-        self.last_status = fold_status(flags[:status.numel()])
+        words, found, is_nonpoint, best_host = hand_off(best, best_ok, status)
+        if is_nonpoint:
+            raise NotImplementedError(f'{where} starts from point states (all-zero Q), as CemSafeMPC.get_action does')
+        self.last_status = fold_status(words)
         both = _lib.SX_STATUS_NAN | _lib.SX_STATUS_ZERO_FIX
         if (self.last_status & both) == both and self._last_noise is not None:
             # The fused kernel lifts exact-zero variances per particle; the reference decides on the whole batch: with a
@@ -518,37 +531,34 @@ class FusedCemMpc:
             # the solve with the same draws through the step-by-step path, which follows the reference's rule.
             self.stepwise_fallbacks += 1
             best, best_ok, history, status = self.solve(x0, noise=self._last_noise, stepwise=True)
-            flags = torch.cat((status, best_ok)).cpu()
-            self.last_status = fold_status(flags[:status.numel()])
+            words, found, _, best_host = hand_off(best, best_ok, status)
+            self.last_status = fold_status(words)
         raise_for_status(self.last_status, where,
                          dump=lambda: save_failure_state(self._ssm, x0, self._last_actions))
-        return best, flags[status.numel():] != 0, history
+        return best_host, found, history
 
     def get_actions_batch(self, states: Tensor) -> Tuple[Tensor, Tensor, List[Rollouts]]:
         """E independent episodes at once (BASELINE config 5): flat start states [E x (n_s + n_s^2)], all
         points.  One fused solve: the kernels carry the episode dimension, episodes never exchange anything.
 
-        Returns (actions [E x H x n_u], found bool [E] on the host, rollouts); ``found[e] == False`` is the
+        Returns (actions [E x H x n_u] on the host, found bool [E] on the host, rollouts); ``found[e] == False`` is the
         ``get_actions`` ``None`` of episode e.  Raises like ``get_actions`` if any episode hit a numerical failure.
         """
         n_s = self._ssm.num_states
         if states.dim() != 2 or states.size(1) != n_s + n_s * n_s:
             raise ValueError(f'Wanted shape (E, {n_s + n_s * n_s}), got {tuple(states.shape)}')
-        if bool((states[:, n_s:] != 0).any()):
-            raise NotImplementedError('get_actions_batch starts from point states (all-zero Q), as CemSafeMPC.get_action does')
-        x0 = states[:, :n_s].to(self._device, torch.float64).contiguous()
-        return self._solve_checked(x0, 'get_actions_batch')
+        states = states.to(self._device, torch.float64)
+        return self._solve_checked(states[:, :n_s].contiguous(), 'get_actions_batch', q_block=states[:, n_s:])
 
     def get_actions(self, state: Tensor) -> Tuple[Optional[Tensor], List[Rollouts]]:
-        """state: the flat start state [1 x (n_s + n_s^2)] with an all-zero Q block (a point, safempc_cem.py:234-235)."""
+        """state: the flat start state [1 x (n_s + n_s^2)] with an all-zero Q block (a point, safempc_cem.py:234-235).
+        The selected actions come back on the host (they travel with the solve's one device->host hand-off)."""
         n_s = self._ssm.num_states
         flat = state.reshape(1, -1)
         if flat.size(1) != n_s + n_s * n_s:
             raise ValueError(f'Wanted shape (1, {n_s + n_s * n_s}), got {tuple(state.shape)}')
-        if bool((flat[:, n_s:] != 0).any()):
-            raise NotImplementedError('get_actions starts from a point state (all-zero Q), as CemSafeMPC.get_action does')
-        x0 = flat[:, :n_s].to(self._device, torch.float64).contiguous()
-        best, found, history = self._solve_checked(x0, 'get_actions')
+        flat = flat.to(self._device, torch.float64)
+        best, found, history = self._solve_checked(flat[:, :n_s].contiguous(), 'get_actions', q_block=flat[:, n_s:])
         if not bool(found[0]):
             return None, history
         return best[0], history

@@ -18,3 +18,13 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f'enqueue {1e3*(t1-t0)/n:.3f} ms/solve, total {1e3*(t2-t0)/n:.3f} ms/solve')
+
+# the latency a control loop sees: get_actions = flat state in, solve, ONE device->host hand-off (status + flags), actions out
+flat = torch.zeros((1, 6), dtype=torch.float64, device=dev)
+flat[0, :2] = x0[0]
+for _ in range(3): mpc.get_actions(flat)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n): mpc.get_actions(flat)
+t1 = time.perf_counter()
+print(f'get_actions (synchronous, one solve at a time): {1e3*(t1-t0)/n:.3f} ms per call')

@@ -93,6 +93,10 @@ def mlp_flops_per_particle_step(widths, d_in, n_s, n_out, members):
     return 2 * members * (fwd + n_s * bwd)
 
 
+def PROFILE_STRIDE(cfg):
+    return 1 if cfg == 4 else 16
+
+
 def pmc_summary(cfg):
     """The committed rocprofv3 --pmc summary for this config (profiles/r02_pmc_cfg<N>.json), or None.  bench.py cannot
     collect PMC counters itself; the numbers are only reported for the workload they were collected on."""
@@ -242,6 +246,10 @@ def main():
     ap.add_argument('--ssm', default='gp', choices=['gp', 'mc_dropout'],
                     help='state-space model: the exact GP of the BASELINE configs, or (not a BASELINE config) the '
                          'reference\'s default MC-dropout network, 64 x 64 hidden units, 30 members, on the same problem')
+    ap.add_argument('--rccl-one-rank', action='store_true',
+                    help='with --gpus 1: run the SHARDED code path (local ranking, RCCL collective, global ranking) over an nccl '
+                         'group of one rank -- the fixed cost of the exchange without any inter-GPU latency')
+    ap.add_argument('--no-exchange-timer', action='store_true', help='no events around the multi-GPU exchange (exchange_us null)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true', help='leave the per-launch HIP events off (no roofline object)')
     args = ap.parse_args()
@@ -279,6 +287,14 @@ def main():
         else:
             dist.init_process_group('gloo')
         group = dist.group.WORLD
+    force_exchange = False
+    if args.rccl_one_rank:
+        if world != 1 or args.config == 5:
+            raise SystemExit('--rccl-one-rank goes with --gpus 1 and a sharded workload (configs 1-4)')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        group, force_exchange = dist.group.WORLD, True
 
     w = problems.baseline_workload(args.config, n_gpus=world, n_train=args.n_train or None)
     spec = w.spec
@@ -308,7 +324,7 @@ def main():
                          torch.tensor(spec.Y, dtype=torch.float64, device=dev), replace_old=True)
     if w.sharded:
         # ONE problem, particles sharded over the GPUs; the elite count does not grow with the GPU count: every rank
-        # contributes its local top-k rows, so the per-iteration all-reduce stays at G x k x (2 + H n_u) doubles
+        # contributes its local top-k rows, so the per-iteration all-gather stays at G x (k + 1) x (2 + H n_u) doubles
         E, total_particles, solver_group = 1, P * world, group
         x0 = torch.tensor(w.x0[:1], dtype=torch.float64, device=dev)
     else:
@@ -326,9 +342,10 @@ def main():
 
     def start_timer():
         if not args.no_kernel_timer:
-            # HIP events on every 4th launch of each kernel (every launch of the large-N path, whose kernels run for
-            # milliseconds): timing every 130 us launch costs the solve ~7 % (measured), every 4th < 2 %
-            _lib.check(lib.sx_profile_stride(1 if w.cfg == 4 else 4), 'sx_profile_stride')
+            # HIP events on every 16th launch of each kernel (every launch of the large-N path, whose kernels run for
+            # milliseconds): timing every 130 us launch costs the solve ~7 % (measured), every 4th 2.6 % (1.121 against
+            # 1.092 ms with the timer off), every 16th < 1 % -- 50 timed launches per kernel in the default run
+            _lib.check(lib.sx_profile_stride(PROFILE_STRIDE(w.cfg)), 'sx_profile_stride')
             _lib.check(lib.sx_profile_enable(max(4096, steps * iters * (3 * H + 4))), 'sx_profile_enable')
 
     if w.cfg == 5:
@@ -359,11 +376,12 @@ def main():
         assert all(r.episode_length == steps for r in episodes)
     else:
         mpc = FusedCemMpc(ssm, env, H, total_particles, elites, iters, device=dev, seed=1, init_std=init_std,
-                          warm_start='safe_policy' if w.warm_start != 'zero' else 'zero', process_group=solver_group)
+                          warm_start='safe_policy' if w.warm_start != 'zero' else 'zero', process_group=solver_group,
+                          force_exchange=force_exchange)
         for _ in range(warmup):
             mpc.solve(x0)
         start_timer()
-        if world > 1 and w.sharded:
+        if ((world > 1 and w.sharded) or force_exchange) and not args.no_exchange_timer:
             mpc.exchange_events = []
         barrier()
         t0 = time.perf_counter()
@@ -400,7 +418,7 @@ def main():
             particle_steps = (P * world if w.sharded else P * episodes_total) * H * iters * steps
             flops_unit = algorithmic_flops_per_particle_step(spec.n_s, n_train, d_in) if mlp is None else \
                 mlp_flops_per_particle_step(mlp['hidden'], d_in, spec.n_s, spec.n_s, mlp['members'])
-            stride = 1 if w.cfg == 4 else 4      # every stride-th launch of a kernel is timed (start_timer)
+            stride = PROFILE_STRIDE(w.cfg)       # every stride-th launch of a kernel is timed (start_timer)
             per_kernel = {k: {'avg_launch_us': ms / n * 1e3, 'launches_timed': n,
                               'share_of_step': min(1.0, ms * stride / (elapsed * 1e3))}
                           for k, (ms, n) in kernels.items()}
@@ -437,7 +455,7 @@ def main():
                 if w.cfg == 2 and mlp is None:
                     out['cpu_baseline']['reference_measured_elsewhere'] = REFERENCE_CPU
             os.write(json_fd, (json.dumps(out) + '\n').encode())
-    if world > 1:
+    if world > 1 or force_exchange:
         dist.barrier(group)
         dist.destroy_process_group()
     sys.exit(rc)

@@ -262,7 +262,7 @@ class FusedCemMpc:
 
     def __init__(self, ssm: GpCemSSM, env: _lib.SxEnv, time_horizon: int, num_rollouts: int, num_elites: int,
                  num_iterations: int, *, device=None, seed: int = 0, init_std=1.0, warm_start: str = 'zero',
-                 record_rollouts: bool = False, process_group=None):
+                 record_rollouts: bool = False, process_group=None, force_exchange: bool = False):
         self._ssm = ssm
         self._env = env
         self._horizon = time_horizon
@@ -279,6 +279,9 @@ class FusedCemMpc:
         self._warm_start = warm_start
         self._group = process_group
         self._world, self._rank = distributed.world_and_rank(process_group)
+        # force_exchange: take the sharded code path (local ranking -> collective -> global ranking) even with ONE rank -- how
+        # tests/test_gpu_distributed.py runs that path over RCCL (backend 'nccl') on a single-GPU box
+        self._sharded = self._world > 1 or (force_exchange and process_group is not None)
         self._num_rollouts = num_rollouts
         self._local_rollouts, _ = distributed.shard_particles(num_rollouts, self._world, self._rank)
         if num_elites > num_rollouts:
@@ -292,7 +295,7 @@ class FusedCemMpc:
         self._local_elites = num_elites     # the same k on every rank
         if num_elites > RANK_MAX_ELITES:
             raise ValueError(f'num_elites={num_elites} exceeds the ranking kernel\'s limit of {RANK_MAX_ELITES}')
-        if self._world > 1 and self._world * (num_elites + 1) > RANK_MAX_CANDIDATES:
+        if self._sharded and self._world * (num_elites + 1) > RANK_MAX_CANDIDATES:
             raise ValueError(f'{self._world * (num_elites + 1)} candidate rows after the exchange exceed the ranking kernel\'s '
                              f'limit of {RANK_MAX_CANDIDATES}')
         chunks = rank_chunks(self._local_rollouts)     # > 1: two-level ranking on this GPU (cem_rank_refit_any)
@@ -368,6 +371,18 @@ class FusedCemMpc:
         self._status_next += 1
         return pool[i:i + 1]
 
+    def _exchange(self, episodes: int, k: int, row_len: int, dev):
+        """The exchange buffers of a solve.  One problem (all-gather mode): every cell is overwritten by each solve and the
+        padding rows never change, so the object is built once and kept -- four small launches per solve otherwise.  Several
+        problems (all-reduce over zero padding): fresh, zeroed buffers per solve."""
+        if episodes != 1:
+            return distributed.EliteExchange(self._num_iterations, episodes, k, row_len, self._group, dev)
+        key = (k, row_len, str(dev))
+        cache = self.__dict__.setdefault('_xch_cache', {})
+        if key not in cache:
+            cache[key] = distributed.EliteExchange(self._num_iterations, 1, k, row_len, self._group, dev)
+        return cache[key]
+
     def _next_noise(self, episodes: int) -> Tensor:
         """[iters x E x P_local x H x n_u] standard normals for one solve, from this solver's generator.  They are drawn for
         up to 8 solves per generator launch (at most 256 MB): one launch per solve is 8 us + a 6 us gap in front of the first
@@ -430,7 +445,7 @@ class FusedCemMpc:
         # From the second iteration on the refit happens in the rollout kernel's prologue, straight from the elite rows of
         # the ranking before it (sx_cem_rollout_elites): the ranking launches then skip their refit tail.
         chunks = rank_chunks(self._local_rollouts)
-        final_candidates = (self._world * (self._local_elites + (1 if E == 1 else 0)) if self._world > 1
+        final_candidates = (self._world * (self._local_elites + (1 if E == 1 else 0)) if self._sharded
                             else chunks * self._num_elites if chunks > 1 else self._local_rollouts)
         in_prologue = (not stepwise) and fused_refit_applies(self._ssm, E, self._local_rollouts, H, final_candidates)
         rows = None
@@ -464,13 +479,13 @@ class FusedCemMpc:
             if self.rollout_events is not None:
                 ev[1].record(torch.cuda.current_stream(dev))
                 self.rollout_events.append(ev)
-            if self._world == 1:
+            if not self._sharded:
                 out = cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], self._num_elites,
                                          want_rows=in_prologue, want_refit=not in_prologue)
             else:
                 k = self._local_elites
                 if xch is None:
-                    xch = distributed.EliteExchange(self._num_iterations, E, k, L, self._group, dev)
+                    xch = self._exchange(E, k, L, dev)
                 if E == 1:
                     # the local elite rows go straight into this rank's slot: no copy between the kernel and the collective
                     cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], k, want_refit=False,

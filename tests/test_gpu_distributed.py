@@ -1,6 +1,8 @@
 """GPU, 2 processes sharing the one card, gloo group: the sharded solve end to end (local rollout on the HIP path, local
-elite rows, one all-reduce, global ranking on every rank) equals the oracle's solve over the union of the particles,
-bit-identically on both ranks.  (The driver's multi-GPU run uses the same code with backend nccl = RCCL.)"""
+elite rows, one collective, global ranking on every rank) equals the oracle's solve over the union of the particles,
+bit-identically on both ranks.  The driver's multi-GPU run uses the same code with backend nccl = RCCL; NCCL wants one
+device per rank, so on this single-GPU box the RCCL calls themselves are exercised with a group of ONE rank
+(test_rccl_single_rank_exchange_and_sharded_path)."""
 import os
 import socket
 
@@ -78,3 +80,59 @@ def test_sharded_solve_two_ranks():
         out = mgr.dict()
         mp.spawn(_worker, args=(port, out), nprocs=WORLD, join=True)
         assert len(out) == WORLD and out[0] == out[1]        # every rank holds the same bytes
+
+
+def _rccl_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        from oracle import cem as ocem
+        from oracle.gp import ExactGP
+        from safe_exploration_amd import distributed, problems
+        from safe_exploration_amd.cem_mpc import FusedCemMpc
+        dev = torch.device('cuda:0')
+        assert dist.get_backend() == 'nccl'
+        # the collectives as EliteExchange issues them: all-gather of the (k + 1)-row blocks (one problem), all-reduce over
+        # the zero-padded slots (two problems), status words riding along
+        rng = np.random.default_rng(2)
+        for E in (1, 2):
+            k, L = 7, 5
+            xch = distributed.EliteExchange(2, E, k, L, dist.group.WORLD, dev)
+            rows = rng.normal(size=(E, k, 2 + L))
+            xch.local_slot(1).copy_(torch.tensor(rows, device=dev))
+            cand, words = xch.exchange(1, torch.tensor([6], dtype=torch.int32, device=dev))
+            torch.cuda.synchronize()
+            assert words.tolist() == [6] and tuple(cand.shape) == (E, xch.candidates, 2 + L)
+            np.testing.assert_array_equal(cand[:, :k].cpu().numpy(), rows)
+            if E == 1:
+                assert bool(torch.isnan(cand[0, k, :2]).all())          # the padding / status row
+        # the solver's sharded code path (local ranking -> RCCL collective -> global ranking -> prologue refit) on one rank
+        spec = problems.pendulum(n_train=90, seed=4, obj_mode=1)
+        ssm, env = problems.build(spec, dev)
+        P, H, k, iters = 192, 5, 16, 3
+        noise = rng.normal(size=(iters, P, H, 1))
+        x0 = np.array([0.015, -0.02])
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+        mpc = FusedCemMpc(ssm, env, H, P, k, iters, device=dev, init_std=0.2, process_group=dist.group.WORLD,
+                          force_exchange=True)
+        best, ok, _, status = mpc.solve(t(x0[None]), noise=t(noise[:, None]))
+        torch.cuda.synchronize()
+        gp = ExactGP(spec.X, spec.Y, spec.lengthscale, spec.outputscale, spec.noise)
+        ref, _ = ocem.cem_solve(problems.oracle_problem(spec, ocem), gp, x0, noise, k, init_std=np.full((H, 1), 0.2))
+        assert tuple(status.shape) == (1,) and not bool(status.any()) and ref is not None and int(ok[0]) == 1
+        np.testing.assert_allclose(best[0].cpu().numpy(), ref, rtol=0, atol=1e-9)
+        out[0] = 'ok'
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_single_rank_exchange_and_sharded_path():
+    """backend 'nccl' IS RCCL on ROCm: the exchange's collectives and the solver's sharded path over it, with a group of one
+    rank (all this box can host).  What it cannot show is the time the collective takes across GPUs."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
+        assert out.get(0) == 'ok'

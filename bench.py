@@ -9,10 +9,11 @@ children (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, nothi
 exits with the worst child's code; under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are already
 there and nothing is spawned.
 
-One STEP = one complete MPC solve (`get_action`'s optimiser call): `iterations` CEM iterations, each = draw the action
-noise, roll all particles out for H steps (GP predict + one-step reachability + costs), rank, refit.  Weak scaling:
+One STEP = one complete MPC solve (`get_action`'s optimiser call): `iterations` CEM iterations, each = sample the actions,
+roll all particles out for H steps (GP predict + one-step reachability + costs), rank, refit; the solver draws the standard
+normals of 8 solves per generator launch, inside the timed region like everything else.  Weak scaling:
 every GPU holds the workload's per-GPU particle count; configs 2-4 shard ONE problem's particles and exchange elite rows
-with ONE all-reduce per iteration, config 5 stripes independent episodes (no collective).  Inputs are synthetic (seeded)
+with ONE all-gather per iteration, config 5 stripes independent episodes (no collective).  Inputs are synthetic (seeded)
 and resident in HBM before the timed region.  Rank 0 prints ONE JSON line; a non-zero device status (the reference would
 have raised ValueError on this workload) is an error, not a throughput.
 """
@@ -439,7 +440,7 @@ def main():
                                        + (f' ({w.notes})' if w.notes else ''),
                            'baseline_config': w.cfg, 'particles_per_gpu': P, 'episodes_per_gpu': E, 'horizon': H,
                            'n_train': n_train, 'cem_iterations': iters, 'elites': elites, 'warm_start': w.warm_start,
-                           'parallelism': (f'particle-sharded x{world}, 1 all-reduce/iteration' if w.sharded
+                           'parallelism': (f'particle-sharded x{world}, 1 all-gather/iteration' if w.sharded
                                            else f'episodes striped x{world}, no collective; lockstep runner '
                                                 f'(episode_runner.do_rollout_batch)'),
                            'backend': args.backend if world > 1 else None},

@@ -256,7 +256,7 @@ class FusedCemMpc:
     """Drop-in for ``ConstrainedCemMpc``: ``get_actions(flat_state [1 x S]) -> (actions [H x n_u] | None, rollouts)``.
 
     With a process group of G > 1 ranks the particles are sharded (``num_rollouts`` is the GLOBAL count): every rank
-    rolls out its share, keeps its local top-k rows, ONE all-reduce per iteration assembles the G*k candidates, and
+    rolls out its share, keeps its local top-k rows, ONE all-gather per iteration assembles the G*(k+1) candidate rows, and
     every rank redundantly ranks them and refits -- bit-identical on all ranks.
     """
 

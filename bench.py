@@ -293,7 +293,11 @@ def main():
         if world != 1 or args.config == 5:
             raise SystemExit('--rccl-one-rank goes with --gpus 1 and a sharded workload (configs 1-4)')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         group, force_exchange = dist.group.WORLD, True
 

@@ -444,6 +444,8 @@ def main():
                                        + (f' ({w.notes})' if w.notes else ''),
                            'baseline_config': w.cfg, 'particles_per_gpu': P, 'episodes_per_gpu': E, 'horizon': H,
                            'n_train': n_train, 'cem_iterations': iters, 'elites': elites, 'warm_start': w.warm_start,
+                           'ranking': ('cem_rank_count_kernel (counting, whole chip)' if int(lib.sx_cem_rank_counts(E, P)) == 1
+                                       else 'cem_rank_kernel (one workgroup per problem)') + '; timed as cem_rank_kernel',
                            'parallelism': (f'particle-sharded x{world}, 1 all-gather/iteration' if w.sharded
                                            else f'episodes striped x{world}, no collective; lockstep runner '
                                                 f'(episode_runner.do_rollout_batch)'),

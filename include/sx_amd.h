@@ -283,6 +283,15 @@ int sx_cem_rollout_elites(const sx_gp_model* model, const sx_env* env, int E, in
  * < 0 = bad arguments. */
 int64_t sx_cem_rollout_workspace_bytes(const sx_gp_model* model, int E, int P, int H);
 
+/* The ONE device -> host hand-off of a solve, packed by one launch: out dev double [G + E + 1 + E*row_len] =
+ *   [status words of the G ranks | best_ok[E] | 1.0 if any of the `q_count` doubles at `q_block` is non-zero | best [E x row_len]]
+ * (q_block may be NULL: the flag is 0).  The caller copies `out` to the host once and reads everything from it.
+ * Replaces: the synchronisations of CemSafeMPC.get_action (safempc_cem.py:231-263): PQFlattener's `q.nonzero()` scan
+ * (:69-71), the optimiser's return value and the failure check of gp_reachability_pytorch.py:149-153, each a trip of its own
+ * in the reference. */
+int sx_cem_pack_result(int G, int E, int row_len, const int32_t* status, const int32_t* best_ok, const double* q_block,
+                       int64_t q_count, const double* best, double* out, void* stream);
+
 /* 1 if sx_cem_rank_refit ranks E problems of P candidates by counting over the whole chip (elite rows in rank order), 0 if
  * by one workgroup per problem (best first, then index order).  Depends on (E, P) only.  A caller that moves the refit into
  * the next rollout (sx_cem_rollout_elites) does so where this returns 1: with many problems at once the one-workgroup

@@ -524,14 +524,27 @@ class FusedCemMpc:
         status words, the feasibility flags, the selected actions and "is any entry of `q_block` non-zero" (the callers'
         point-state check, evaluated on the device and read here instead of in a synchronisation of its own before the
         solve).  Returns (best [E x H x n_u] ON THE HOST, found bool [E] on the host, rollouts)."""
-        nonpoint = ((q_block != 0).any().reshape(1).to(torch.float64) if q_block is not None
-                    else torch.zeros(1, dtype=torch.float64, device=x0.device))
+        if q_block is not None and not q_block.is_contiguous():
+            q_block = q_block.contiguous()
 
         def hand_off(best, best_ok, status):
-            G, E = status.numel(), best_ok.numel()
-            packed = torch.cat((status.to(torch.float64), best_ok.to(torch.float64), nonpoint, best.reshape(-1))).cpu()
-            return (packed[:G].to(torch.int64), packed[G:G + E] != 0, bool(packed[G + E] != 0),
-                    packed[G + E + 1:].view(best.shape))
+            # one launch packs [status words | flags | point-state check | actions], one copy into pinned memory brings
+            # them over (sx_cem_pack_result)
+            G, E, L = status.numel(), best_ok.numel(), best[0].numel()
+            n = G + E + 1 + E * L
+            packed = torch.empty(n, dtype=torch.float64, device=best.device)
+            _lib.check(_lib.lib().sx_cem_pack_result(G, E, L, _lib.ptr(status), _lib.ptr(best_ok), _lib.ptr(q_block),
+                                                     q_block.numel() if q_block is not None else 0,
+                                                     _lib.ptr(best.contiguous()), _lib.ptr(packed),
+                                                     _lib.stream_ptr(best.device)), 'sx_cem_pack_result')
+            host = getattr(self, '_pinned', None)
+            if host is None or host.numel() < n:
+                self._pinned = host = torch.empty(max(n, 256), dtype=torch.float64).pin_memory()
+            host[:n].copy_(packed, non_blocking=True)
+            torch.cuda.current_stream(best.device).synchronize()
+            out = host[:n].clone()
+            return (out[:G].to(torch.int64), out[G:G + E] != 0, bool(out[G + E] != 0),
+                    out[G + E + 1:].view(best.shape))
 
         best, best_ok, history, status = self.solve(x0)
         words, found, is_nonpoint, best_host = hand_off(best, best_ok, status)

@@ -1188,6 +1188,36 @@ int sx_cem_rollout_mlp(const sx_mlp_model* model, const sx_env* env, int E, int 
 #undef CALL
 }
 
+namespace sx {
+// sx_cem_pack_result: one small workgroup
+__global__ __launch_bounds__(256) void pack_result_kernel(int G, int E, int L, const int* __restrict__ status,
+                                                          const int* __restrict__ best_ok, const double* __restrict__ q_block,
+                                                          long long q_count, const double* __restrict__ best,
+                                                          double* __restrict__ out) {
+    __shared__ int any_nz;
+    const int tid = threadIdx.x;
+    if (tid == 0) any_nz = 0;
+    __syncthreads();
+    int nz = 0;
+    if (q_block)
+        for (long long i = tid; i < q_count; i += blockDim.x) nz |= (q_block[i] != 0.0) ? 1 : 0;   // (NaN counts as non-zero)
+    if (nz) atomicOr(&any_nz, 1);
+    for (int i = tid; i < G; i += blockDim.x) out[i] = (double)status[i];
+    for (int i = tid; i < E; i += blockDim.x) out[G + i] = (double)best_ok[i];
+    for (int i = tid; i < E * L; i += blockDim.x) out[G + E + 1 + i] = best[i];
+    __syncthreads();
+    if (tid == 0) out[G + E] = any_nz ? 1.0 : 0.0;
+}
+}  // namespace sx
+
+int sx_cem_pack_result(int G, int E, int row_len, const int32_t* status, const int32_t* best_ok, const double* q_block,
+                       int64_t q_count, const double* best, double* out, void* stream) {
+    if (G <= 0 || E <= 0 || row_len <= 0 || !status || !best_ok || !best || !out || q_count < 0) return SX_ERR_ARG;
+    hipLaunchKernelGGL(sx::pack_result_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, G, E, row_len, status, best_ok,
+                       q_count > 0 ? q_block : nullptr, (long long)q_count, best, out);
+    return sx::check_launch();
+}
+
 // Which ranking kernel: by shape only (every rank of a multi-GPU solve must take the same one: the elite order differs).
 // Counting spreads one or two problems over the chip (E P / 16 workgroups, all keys in each one's LDS); many problems at
 // once already fill it with the one-workgroup kernel (SX_RANK_PATH = count | select overrides, for A/B measurements).

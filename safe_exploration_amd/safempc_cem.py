@@ -305,10 +305,16 @@ class CemSafeMPC(SafeMPC):
         self._env_key = key
         return self._mpc
 
+    def _flat_points(self, states: ndarray) -> Tensor:
+        """Point states [E x n_s] as the optimiser's flat states [E x (n_s + n_s^2)] (PQFlattener.flatten(p, None): an
+        all-zero Q block), assembled on the host: ONE host->device copy instead of a copy, a fill and a concatenation."""
+        flat = np.zeros((states.shape[0], self._pq_flattener.get_flat_state_dimen()), dtype=np.float64)
+        flat[:, :self._state_dimen] = states
+        return torch.tensor(flat, device=self._device)
+
     def get_action(self, state: ndarray) -> Tuple[ndarray, MpcResult]:
         assert_shape(state, (self._state_dimen,))
-        state_batch = torch.tensor(state, device=self._device).unsqueeze(0)
-        mpc_actions, rollouts = self._solver().get_actions(self._pq_flattener.flatten(state_batch, None))
+        mpc_actions, rollouts = self._solver().get_actions(self._flat_points(np.asarray(state)[None]))
         mpc_actions = mpc_actions.detach().cpu().numpy() if mpc_actions is not None else mpc_actions
         self.last_rollouts = rollouts
         # the reference's ladder (safempc_cem.py:243-263): fresh solution, else the rest of the previous one, else the
@@ -346,8 +352,7 @@ class CemSafeMPC(SafeMPC):
         if self._batch_last_actions is None or len(self._batch_last_actions) != E:
             self._batch_last_actions = [np.empty((0, self.action_dimen)) for _ in range(E)]
             self._batch_executed = [0] * E
-        state_batch = torch.tensor(states, device=self._device)
-        best, found, rollouts = self._solver().get_actions_batch(self._pq_flattener.flatten(state_batch, None))
+        best, found, rollouts = self._solver().get_actions_batch(self._flat_points(states))
         best = best.detach().cpu().numpy()
         self.last_rollouts = rollouts
         actions: List[ndarray] = []

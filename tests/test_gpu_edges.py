@@ -253,3 +253,34 @@ def test_failure_dump_is_written_before_the_value_error(tmp_path, monkeypatch):
     other = GpCemSSM(Conf(), 2, 1)
     other.load_state_dict(ssm.state_dict())
     assert torch.equal(other.lengthscale, ssm.lengthscale) and torch.equal(other.noise, ssm.noise)
+
+
+def test_pack_result_is_the_one_hand_off_of_a_solve():
+    """sx_cem_pack_result: status words, feasibility flags, the point-state check and the selected actions in one buffer
+    (what get_actions / get_actions_batch copy to the host, once)."""
+    import ctypes
+    from safe_exploration_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(0)
+    for G, E, L, q in [(1, 1, 15, None), (8, 1, 30, np.zeros(4)), (1, 5, 7, np.zeros((5, 16))), (2, 3, 4, 'nonzero'),
+                       (1, 2, 3, 'nan')]:
+        status = torch.tensor(rng.integers(0, 8, size=G), dtype=torch.int32, device=dev)
+        ok = torch.tensor(rng.integers(0, 2, size=E), dtype=torch.int32, device=dev)
+        best = torch.tensor(rng.normal(size=(E, L)), dtype=torch.float64, device=dev)
+        if isinstance(q, str):
+            qb = np.zeros(1000)
+            qb[777] = np.nan if q == 'nan' else -1e-300
+            want_flag = 1.0
+        else:
+            qb, want_flag = q, 0.0
+        qt = None if qb is None else torch.tensor(np.asarray(qb).reshape(-1), dtype=torch.float64, device=dev)
+        out = torch.full((G + E + 1 + E * L,), 7.0, dtype=torch.float64, device=dev)
+        _lib.check(lib.sx_cem_pack_result(G, E, L, _lib.ptr(status), _lib.ptr(ok), _lib.ptr(qt), 0 if qt is None else qt.numel(),
+                                          _lib.ptr(best), _lib.ptr(out), _lib.stream_ptr(dev)), 'sx_cem_pack_result')
+        got = out.cpu().numpy()
+        np.testing.assert_array_equal(got[:G], status.cpu().numpy().astype(np.float64))
+        np.testing.assert_array_equal(got[G:G + E], ok.cpu().numpy().astype(np.float64))
+        assert got[G + E] == want_flag
+        np.testing.assert_array_equal(got[G + E + 1:], best.cpu().numpy().reshape(-1))
+    assert lib.sx_cem_pack_result(0, 1, 1, None, None, None, 0, None, None, None) == _lib.SX_ERR_ARG

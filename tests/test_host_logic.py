@@ -345,3 +345,34 @@ class TestJunkDimensionsSSM:   # test_ssm_cem.py:116-168
         assert ssm.x_train.size() == (4, 3) and ssm.y_train.size() == (4, 2)
         with pytest.raises(ValueError):
             ssm.predict_raw(torch.empty((3, 4)))
+
+
+def test_solver_draws_noise_for_several_solves_at_once_and_pools_status_words():
+    """Host bookkeeping of FusedCemMpc that needs no GPU: the standard normals of up to 8 solves come from ONE generator
+    launch (distinct slices, redrawn when the pool is used up or the episode count changes), the status words are slices of
+    a zeroed pool handed out once each, constants are built once per (name, episodes)."""
+    from safe_exploration_amd.cem_mpc import FusedCemMpc
+
+    class _Ssm:
+        num_states, num_actions = 2, 1
+
+    mpc = FusedCemMpc(_Ssm(), None, 5, 64, 8, 3, device='cpu', seed=7)
+    first = [mpc._next_noise(1) for _ in range(8)]
+    assert all(tuple(n.shape) == (3, 1, 64, 5, 1) and n.dtype == torch.float64 for n in first)
+    assert len({n.data_ptr() for n in first}) == 8 and first[0].data_ptr() == mpc._noise_pool.data_ptr()
+    assert not torch.equal(first[0], first[1])
+    pool = mpc._noise_pool
+    again = mpc._next_noise(1)                                   # the ninth solve: a new pool
+    assert mpc._noise_pool is not pool and not torch.equal(again, first[0])
+    two = mpc._next_noise(2)                                     # another episode count: a new pool of that shape
+    assert tuple(two.shape) == (3, 2, 64, 5, 1)
+    same_seed = FusedCemMpc(_Ssm(), None, 5, 64, 8, 3, device='cpu', seed=7)._next_noise(1)
+    assert torch.equal(same_seed, first[0])                      # a fresh solver with the same seed repeats the draws
+    words = [mpc._fresh_status(torch.device('cpu')) for _ in range(300)]
+    assert all(int(w.item()) == 0 and tuple(w.shape) == (1,) for w in words)
+    assert len({w.data_ptr() for w in words}) == 300             # every slice handed out once
+    made = []
+    a = mpc._constant('x', 1, 'cpu', lambda: made.append(1) or torch.zeros(3))
+    b = mpc._constant('x', 1, 'cpu', lambda: made.append(1) or torch.zeros(3))
+    c = mpc._constant('x', 2, 'cpu', lambda: made.append(1) or torch.zeros(3))
+    assert a is b and c is not a and len(made) == 2

@@ -209,7 +209,7 @@ def test_rank_refit_vs_oracle(P, k, L):
 
 
 @pytest.mark.parametrize('E,P,k,L', [(1, 2048, 2048, 3), (2, 130, 7, 300), (1, 17, 17, 33), (1, 8192, 819, 30), (1, 8191, 1, 5),
-                                     (2, 4100, 2048, 9)])
+                                     (2, 4100, 2048, 9), (1, 1, 1, 2), (64, 5, 2, 3), (3, 2, 1, 1)])
 def test_rank_by_counting_edge_shapes(E, P, k, L):
     """The multi-workgroup counting kernel (csrc/sx_rank_count.hpp) at its edges: every candidate an elite, rows wider than
     32 / 256 columns, a ragged last tile, the largest candidate count it takes, k = 1, all keys tied (ties go to the lower
@@ -218,10 +218,11 @@ def test_rank_by_counting_edge_shapes(E, P, k, L):
     rng = np.random.default_rng(P + k + L)
     con = rng.choice([0., 0., 3., 10., 13., 20.], size=(E, P))
     obj = rng.normal(size=(E, P))
-    obj[:, ::5] = obj[:, 1:2]                     # many exact ties
+    if P > 1:
+        obj[:, ::5] = obj[:, 1:2]                 # many exact ties
     if E > 1:
         con[1], obj[1] = 3.0, 0.25                # problem 1: every key the same
-    obj[0, 3] = np.nan
+    obj[0, min(3, P - 1)] = np.nan
     con[0, min(9, P - 1)] = np.nan
     act = rng.normal(size=(E, P, L))
     out = cem_rank_refit(T(con), T(obj), T(act), k, want_rows=True)

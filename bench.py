@@ -35,7 +35,9 @@ MFMA_FLOPS = 2048               # one v_mfma_f64_16x16x4_f64 = 16 x 16 x 4 x 2 f
 REFERENCE_CPU = {'value': 1.25e4, 'unit': 'particle-steps/s', 'cores': 8, 'kind': 'reference',
                  'sample': 'gp_reachability_pytorch.onestep_reachability, P=4096 N=200 f64, stand-in exact GP, torch-CPU, '
                            'measured in the build container (SURVEY.md section 6), not on this box'}
-DEFAULT_STEPS = {1: (200, 20), 2: (100, 10), 3: (50, 5), 4: (3, 1), 5: (30, 3)}
+# (steps, warm-up) when no flags are given: about 2 s of GPU time each, long enough for a utilisation sampler to see the run
+# (round 1's default of 100 config-2 solves was 0.13 s inside a 12 s process dominated by the CPU baseline)
+DEFAULT_STEPS = {1: (2000, 50), 2: (2000, 50), 3: (500, 10), 4: (3, 1), 5: (250, 5)}
 
 
 # algorithmic flops per particle-step  F = n_s [2N^2 + 2N + 2N + 2ND + 3ND + N]

@@ -104,10 +104,12 @@ def rollout(prob: Problem, gp, x0, actions, q0=None) -> RolloutResult:
 
 
 def rank(con_cost, obj_cost, k):
-    """Indices of the k best particles: lexicographic (constraint cost, objective cost, index). NaN sorts last."""
-    con = np.where(np.isnan(con_cost), np.inf, con_cost)
-    obj = np.where(np.isnan(obj_cost), np.inf, obj_cost)
-    order = np.lexsort((np.arange(len(con)), obj, con))
+    """Indices of the k best particles: lexicographic (constraint cost, objective cost, index), costs compared as numbers
+    (-0.0 == +0.0); NaN sorts last, strictly behind +inf."""
+    con_nan, obj_nan = np.isnan(con_cost), np.isnan(obj_cost)
+    con = np.where(con_nan, np.inf, con_cost)
+    obj = np.where(obj_nan, np.inf, obj_cost)
+    order = np.lexsort((np.arange(len(con)), obj, obj_nan, con, con_nan))
     return order[:k]
 
 

@@ -31,7 +31,8 @@ constexpr int kRankMaxK = 2048;
 constexpr int kRankSlots = 16;  // candidates per thread held in registers: P <= 16384
 
 __device__ __forceinline__ unsigned long long sortable_key(double x) {
-    if (x != x) return ~0ull;  // NaN last
+    if (x != x) return ~0ull;  // NaN last, behind +inf
+    x += 0.0;                  // -0.0 -> +0.0: the two compare equal, so they must share a key (ties go by index)
     unsigned long long b = (unsigned long long)__double_as_longlong(x);
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }

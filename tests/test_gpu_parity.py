@@ -248,6 +248,35 @@ def test_rank_by_counting_edge_shapes(E, P, k, L):
     np.testing.assert_array_equal(out2['elite_rows'].cpu().numpy(), out['elite_rows'].cpu().numpy())
 
 
+@pytest.mark.parametrize('P', [48, 5000, 12000])       # counting kernel / counting kernel / one workgroup per problem
+def test_rank_order_of_signed_zeros_infinities_and_nans(P):
+    """Costs compare as NUMBERS: -0.0 and +0.0 tie (the lower index wins), -inf < finite < +inf < NaN.  (Found by
+    tools/rank_fuzz.py: the sortable integer keys ordered -0.0 in front of +0.0.)"""
+    from safe_exploration_amd.cem_mpc import cem_rank_refit
+    rng = np.random.default_rng(P)
+    con = rng.choice([0.0, -0.0, 3.0], size=(2, P))
+    obj = rng.choice([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan], size=(2, P))
+    con[1, ::7] = np.nan
+    con[1, 1::7] = np.inf
+    act = rng.normal(size=(2, P, 3))
+    for k in (1, min(P // 3, 2048), min(P, 2048)):
+        out = cem_rank_refit(T(con), T(obj), T(act), k, want_rows=True)
+        for e in range(2):
+            want = ocem.rank(con[e], obj[e], k)
+            got = out['elite_idx'][e].cpu().numpy()
+            assert got[0] == want[0] and set(got.tolist()) == set(want.tolist())
+
+
+def test_rank_fuzz_small():
+    """A short run of tools/rank_fuzz.py (random shapes, ties, NaNs, infinities, strided candidate rows; both kernels)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rank_fuzz.py'), '80', '5'], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize('E,P,H,k', [(1, 100, 7, 13), (3, 64, 15, 64), (1, 40, 5, 1), (2, 33, 12, 700)])
 def test_rollout_refits_from_elite_rows(E, P, H, k):
     """sx_cem_rollout_elites: the sampling distribution refit from elite rows in the rollout kernel's prologue equals the

@@ -275,3 +275,14 @@ def test_dropout_ensemble_oracle():
     h = np.maximum(np.maximum(z @ layers[0][0].T + layers[0][1], 0) @ layers[1][0].T + layers[1][1], 0)
     np.testing.assert_allclose(m1, (h @ layers[2][0].T + layers[2][1])[:, :2], rtol=1e-13)
     assert (v1 == 0).all()
+
+
+def test_oracle_rank_orders_numbers_and_puts_nan_last():
+    """oracle.cem.rank (the CEM loop is this repository's own specification): lexicographic (constraint cost,
+    objective cost, index) on the costs as numbers -- signed zeros tie -- with NaN strictly behind +inf."""
+    from oracle import cem as ocem
+    con = np.array([0.0, -0.0, 0.0, np.nan, np.inf, 3.0, -np.inf])
+    obj = np.array([1.0, 1.0, -0.0, 0.0, 0.0, np.nan, 5.0])
+    np.testing.assert_array_equal(ocem.rank(con, obj, 7), [6, 2, 0, 1, 5, 4, 3])
+    obj2 = np.array([np.nan, np.inf, 0.0, -0.0, -np.inf, 2.0, 2.0])
+    np.testing.assert_array_equal(ocem.rank(np.zeros(7), obj2, 7), [4, 2, 3, 5, 6, 1, 0])

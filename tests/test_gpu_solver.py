@@ -555,6 +555,23 @@ def test_other_state_action_dimensions(n_s, n_u):
     np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
     assert int(r['status'].item()) == ref.status == 0
     assert (ref.con_cost > 0).any()
+    # the refit in the rollout's prologue (sx_cem_rollout_elites) at these dimensions: few and many elite rows (the many
+    # are read in several batches and again for the second pass)
+    from safe_exploration_amd.cem_mpc import fused_refit_applies
+    for k, H2 in ((37, 9), (1500, 6)):
+        assert fused_refit_applies(ssm, 2, 48, H2)
+        rows = np.concatenate([np.zeros((2, k, 2)), rng.normal(0.05, 0.2, size=(2, k, H2 * n_u))], axis=2)
+        noise = rng.normal(size=(2, 48, H2, n_u))
+        x02 = rng.normal(0, 0.02, size=(2, n_s))
+        r1 = cem_rollout(ssm, env, T(x02), H2, elite_rows=T(rows), noise=T(noise), want_dist=True)
+        for e in range(2):
+            m, sd = ocem.refit(rows[e, :, 2:].reshape(k, H2, n_u))
+            np.testing.assert_allclose(r1['mean'][e].cpu().numpy(), m, rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(r1['std'][e].cpu().numpy(), sd, rtol=1e-12, atol=1e-15)
+        r2 = cem_rollout(ssm, env, T(x02), H2, mean=r1['mean'], std=r1['std'], noise=T(noise))
+        torch.testing.assert_close(r1['actions'], r2['actions'], rtol=0, atol=0)
+        torch.testing.assert_close(r1['obj_cost'], r2['obj_cost'], rtol=0, atol=0)
+        torch.testing.assert_close(r1['con_cost'], r2['con_cost'], rtol=0, atol=0)
 
 
 def test_batched_episodes_equal_single_solves():

@@ -649,3 +649,14 @@ def test_junk_dimensions_wrapper_over_the_hip_gp():
     np.testing.assert_allclose(jac.cpu().numpy(), jo[:, :2, :3], rtol=1e-9, atol=1e-12)   # leading columns, as the reference
     m2, v2 = ssm.predict_without_jacobians(T(z[:, :2]), T(z[:, 2:]))
     assert torch.equal(m2, mean) and tuple(v2.shape) == (11, 2)
+
+
+def test_solve_fuzz_small():
+    """A short run of tools/solve_fuzz.py: random small problems (training-set size, episodes, particles, horizon, elites,
+    iterations, start spread), whole solves against the oracle's CEM loop with the same noise."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'solve_fuzz.py'), '25', '9'], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

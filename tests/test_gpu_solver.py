@@ -1,5 +1,7 @@
 """GPU: the drop-in classes end to end (CemSafeMPC.get_action, the dynamics callback, the objective hook path, GP
 hyper-parameter fit), checked against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch

@@ -662,3 +662,14 @@ def test_solve_fuzz_small():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'solve_fuzz.py'), '25', '9'], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_rollout_fuzz_small():
+    """A short run of tools/rollout_fuzz.py: GP posterior and fused rollout against the oracle over random training-set sizes
+    (every residue modulo the 16-row blocks, tiny sets, both problems)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rollout_fuzz.py'), '40', '7'], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -136,3 +136,15 @@ def test_rccl_single_rank_exchange_and_sharded_path():
         out = mgr.dict()
         mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
         assert out.get(0) == 'ok'
+
+
+@pytest.mark.timeout(400)
+def test_sharded_solve_fuzz_small():
+    """A short run of tools/dist_fuzz.py: random shapes (uneven shards, elites up to the smaller share, one or two problems)
+    through the two-rank sharded solve, against the oracle over the union of the particles, bit-identical on both ranks."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dist_fuzz.py'), '12', '5'], capture_output=True, text=True,
+                       timeout=380)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -104,6 +104,11 @@ class McDropoutSSM(CemSSM):
         if len(self._hidden) > _lib.SX_MLP_MAX_HIDDEN or (self._hidden and max(self._hidden) > _lib.SX_MLP_MAX_WIDTH):
             raise NotImplementedError(f'mc_dropout_hidden_features={self._hidden}: the device kernel holds up to '
                                       f'{_lib.SX_MLP_MAX_HIDDEN} hidden layers of up to {_lib.SX_MLP_MAX_WIDTH} units')
+        # three and four hidden layers run on the one-particle-per-lane kernel (csrc/sx_mlp.hpp), which keeps
+        # (layers + 2) x widest-layer x 64 doubles in LDS (160 KB): 3 x 64 fits, 4 layers up to 53 units
+        if len(self._hidden) >= 3 and (len(self._hidden) + 2) * max(self._hidden) * 64 * 8 > 160 * 1024:
+            raise NotImplementedError(f'mc_dropout_hidden_features={self._hidden}: with {len(self._hidden)} hidden layers the '
+                                      f'widest may have {160 * 1024 // ((len(self._hidden) + 2) * 64 * 8)} units')
         self._type = conf.mc_dropout_type
         if self._type == 'fixed':
             self._rate = float(conf.mc_dropout_fixed_probability)

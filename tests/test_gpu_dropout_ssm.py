@@ -243,3 +243,19 @@ def test_tiles_straddling_episodes_and_initial_ellipsoids(mlp_path, n_s, hidden,
     np.testing.assert_allclose(out['mfma']['sigma'], out['valu']['sigma'], rtol=1e-8, atol=1e-18)
     np.testing.assert_allclose(out['mfma']['obj_cost'], out['valu']['obj_cost'], rtol=1e-9, atol=1e-13)
     np.testing.assert_array_equal(out['mfma']['con_cost'], out['valu']['con_cost'])
+
+
+def test_deep_networks_beyond_the_lane_kernels_lds_are_refused_at_construction():
+    """Three hidden layers run up to 64 units wide, four up to 53 (the one-particle-per-lane kernel keeps (layers + 2) x
+    widest x 64 doubles in LDS): anything beyond is refused when the model is built, not at the first prediction."""
+    from safe_exploration_amd.ssm_cem.dropout_ssm_cem import McDropoutSSM
+    for hidden in ([64, 64, 64], [53, 20, 53, 8]):
+        ssm = McDropoutSSM(conf(mc_dropout_hidden_features=hidden, mc_dropout_num_samples=3), 2, 1)
+        z = np.random.default_rng(0).normal(0, 0.5, size=(5, 3))
+        m, v, j = ssm.predict_with_jacobians(T(z[:, :2]), T(z[:, 2:]))
+        mo, vo, jo = oracle_of(ssm).predict(z)
+        np.testing.assert_allclose(m.cpu().numpy(), mo, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(j.cpu().numpy(), jo, rtol=1e-9, atol=1e-12)
+    for hidden in ([64, 8, 8, 8], [54, 54, 54, 54], [65], [8, 8, 8, 8, 8]):
+        with pytest.raises(NotImplementedError):
+            McDropoutSSM(conf(mc_dropout_hidden_features=hidden), 2, 1)

@@ -26,6 +26,10 @@ from .ssm_cem import CemSSM
 _NOISE_FLOOR = 1e-4
 
 
+# csrc/sx_fit.hpp kFitMaxN: the factorisation's last stage keeps one column of the system in LDS
+MAX_TRAINING_POINTS = 4096
+
+
 class GpCemSSM(CemSSM):
     kernel_family = 'rbf'   # 'feature' for the degenerate kernels ('linear', 'nn'): feature_gp_ssm_cem.FeatureGpCemSSM
 
@@ -136,11 +140,14 @@ class GpCemSSM(CemSSM):
         return m, linv, alpha, logdet, status
 
     def _update_model(self, x_train: Tensor, y_train: Tensor) -> None:
+        n_s, n_u, n = self.num_states, self.num_actions, x_train.size(0)
+        if n > MAX_TRAINING_POINTS:
+            raise ValueError(f'{n} training points: the exact-GP kernels hold up to {MAX_TRAINING_POINTS} (sx_gp_fit); keep the '
+                             f'most recent / most informative ones (update_model(..., replace_old=True))')
         _lib.require_gpu(x_train, 'train_x')
         _lib.require_gpu(y_train, 'train_y')
         lib = _lib.lib()
         dev = x_train.device
-        n_s, n_u, n = self.num_states, self.num_actions, x_train.size(0)
         x = x_train.detach().contiguous()
         y = y_train.detach().contiguous()
         a_n, t_n = ctypes.c_int64(), ctypes.c_int64()

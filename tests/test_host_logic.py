@@ -376,3 +376,17 @@ def test_solver_draws_noise_for_several_solves_at_once_and_pools_status_words():
     b = mpc._constant('x', 1, 'cpu', lambda: made.append(1) or torch.zeros(3))
     c = mpc._constant('x', 2, 'cpu', lambda: made.append(1) or torch.zeros(3))
     assert a is b and c is not a and len(made) == 2
+
+
+def test_too_many_training_points_are_refused_with_the_limit():
+    """More than 4096 training points: a ValueError that names the limit (it used to surface as the C library's generic
+    "unsupported dimension" from sx_gp_fit)."""
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM, MAX_TRAINING_POINTS
+
+    class Conf:
+        exact_gp_training_iterations, exact_gp_kernel, device = 0, 'rbf', 'cpu'
+
+    ssm = GpCemSSM(Conf(), 2, 1)
+    n = MAX_TRAINING_POINTS + 1
+    with pytest.raises(ValueError, match='4096'):
+        ssm.update_model(torch.zeros((n, 3), dtype=torch.float64), torch.zeros((n, 2), dtype=torch.float64), replace_old=True)

@@ -272,6 +272,8 @@ __device__ __forceinline__ void kstar_pair_range(int total, int before, int weig
 
 typedef __attribute__((address_space(3))) double lds_f64;
 
+#define SX_PIN() __builtin_amdgcn_sched_barrier(0)
+
 template <int NS, int D>
 __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int q_begin, int q_end,
                                                const double (&z)[D]) {
@@ -324,6 +326,132 @@ __device__ __forceinline__ void gp_kstar_phase(const GpConst<NS, D>& gc, GpTileL
         }
         x += 8 * D;
         f += NS * 128;
+    }
+}
+
+// gp_kstar_phase, software-pipelined for ONE wave per SIMD (the register-resident rollout, sx_rollout_rw.hpp).  With two
+// waves per SIMD the two LDS round trips of a trip (the X rows, then the 2^(j/256) table) hide behind the other wave's
+// arithmetic; a lone wave waits them out: 600 cycles per trip measured against 340 of issue.  Here a trip is split in
+// three stages that overlap across trips -- the X rows of trip i + 2 are requested while trip i + 1 computes its
+// exponents and requests its table entries (A1), trip i is finished and stored (B), and trip i + 1 evaluates its
+// polynomial (A2) -- so nothing waits for a load that was not issued a stage earlier.  Two register sets alternate (no
+// moves); the X rows need one set only (the next trip's are requested as soon as A1 has consumed this trip's).  The arithmetic, operation for operation, is exp_tab_f64_n's: the values are bit-identical to gp_kstar_phase's.
+// Reads up to one trip (8 rows of X) past q_end: rows past n_pad are the start of the Kstar buffer (finite or not,
+// their results are never stored).
+template <int NS, int D>
+__device__ __forceinline__ void gp_kstar_phase_pipe(const GpConst<NS, D>& gc, GpTileLds<NS, D>& lds, int q_begin, int q_end,
+                                                    const double (&z)[D]) {
+    constexpr int M = 2 * NS;
+    const int n = q_end - q_begin;
+    if (n <= 0) return;
+    const int lane = (int)threadIdx.x & 63;
+    const int c = lane & 15;
+    double log_os[NS];
+#pragma unroll
+    for (int d = 0; d < NS; ++d) {
+        log_os[d] = gc.k_log_os[d];
+        asm volatile("" : "+v"(log_os[d]));
+    }
+    bool znan = false;
+#pragma unroll
+    for (int j = 0; j < D; ++j) znan = znan || (z[j] != z[j]);
+    const lds_f64* etab = (const lds_f64*)lds.etab + (znan ? kExpTab : 0);
+    const int k0 = 8 * q_begin + (lane >> 4);
+    const lds_f64* x = (const lds_f64*)lds.xs + k0 * D;
+    lds_f64* f = (lds_f64*)lds.kfrag + kfrag_index(NS, c, k0, 0);
+
+    struct Set {
+        double t[M], p[M];   // table entry (in flight after A1); r = y - rint(y) after A1, the polynomial after A2
+        int mi[M];
+    };
+    auto load_x = [&](double (&xx)[2 * D]) {
+        asm volatile("" : "+v"(x));
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < D; ++j) xx[h * D + j] = x[h * 4 * D + j];
+        x += 8 * D;
+    };
+    auto stage_a1 = [&](const double (&xx)[2 * D], Set& s) {
+        double yc[M], m[M];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double sq[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double df = z[j] - xx[h * D + j];
+                sq[j] = df * df;
+            }
+#pragma unroll
+            for (int d = 0; d < NS; ++d) {
+                double a = log_os[d];
+#pragma unroll
+                for (int j = 0; j < D; ++j) a = fma(sq[j], gc.k_nh_ils2[d * D + j], a);
+                yc[h * NS + d] = a;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) yc[i] = __builtin_fmax(yc[i], -800.0 * kExpScale);
+#pragma unroll
+        for (int i = 0; i < M; ++i) m[i] = __builtin_rint(yc[i]);
+#pragma unroll
+        for (int i = 0; i < M; ++i) asm("v_cvt_i32_f64 %0, %1" : "=v"(s.mi[i]) : "v"(m[i]));
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.t[i] = etab[s.mi[i] & (kExpTab - 1)];
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = (yc[i] - m[i]) * kExpUnit;   // r (the difference is exact)
+    };
+    auto stage_a2 = [&](Set& s) {
+        double r[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) r[i] = s.p[i];
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = fma(r[i], 4.16666666666666666667e-02, 1.66666666666666666667e-01);
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = fma(s.p[i], r[i], 0.5);
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = fma(s.p[i], r[i], 1.0);
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = s.p[i] * r[i];
+    };
+    auto stage_b = [&](const Set& s) {
+        asm volatile("" : "+v"(f));
+        double val[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) val[i] = ldexp(fma(s.t[i], s.p[i], s.t[i]), s.mi[i] >> 8);
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+            f[d * 128] = val[d];
+            f[d * 128 + 1] = val[NS + d];
+        }
+        f += NS * 128;
+    };
+    double xr[2 * D];     // the X rows of the next trip to enter A1
+    Set s0, s1;
+    load_x(xr);           // trip 0
+    stage_a1(xr, s0);
+    load_x(xr);           // trip 1
+    stage_a2(s0);
+    // body: sold = trip i (A1 + A2 done), snew <- trip i + 1 (its rows are in xr), xr <- rows of trip i + 2
+    auto body = [&](const Set& sold, Set& snew) {
+        stage_a1(xr, snew);
+        SX_PIN();
+        load_x(xr);
+        stage_b(sold);
+        SX_PIN();
+        stage_a2(snew);
+        SX_PIN();
+    };
+    const int n1 = n - 1;
+    for (int k = 0; k < (n1 >> 1); ++k) {
+        body(s0, s1);
+        body(s1, s0);
+    }
+    if (n1 & 1) {
+        body(s0, s1);
+        stage_b(s1);
+    } else {
+        stage_b(s0);
     }
 }
 
@@ -426,7 +554,6 @@ struct MfmaStage {
     int z, w;
 };
 
-#define SX_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // What a wave needs to open its MFMA phase: the stage count, the descriptors of its first four stages and the W
 // fragments of the first three.  The stream is static, so a kernel fetches all of it ONCE and keeps it in registers:

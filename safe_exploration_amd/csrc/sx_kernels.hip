@@ -18,6 +18,8 @@
 #include "sx_fit.hpp"
 #include "sx_fit_blocked.hpp"
 #include "sx_rollout.hpp"
+#include "sx_launch.hpp"
+#include "sx_rw_launch.hpp"
 #include "sx_rank.hpp"
 #include "sx_rank_count.hpp"
 #include "sx_feat.hpp"
@@ -26,7 +28,9 @@
 
 namespace sx {
 
-constexpr size_t kMaxLdsBytes = 160 * 1024;
+#ifdef SX_STAMPS
+static unsigned long long* g_stamp_host = nullptr;   // diagnostic build: the phase-stamp buffer (sx_debug_set_stamps)
+#endif
 
 constexpr int kPredictThreads = 64 * SX_WAVES;
 
@@ -296,7 +300,7 @@ static std::vector<ProfEntry> g_prof_entries;
 static std::vector<hipEvent_t> g_prof_pool;
 
 // Takes a (start, stop) event pair for one launch of kernel class `kind`, or returns false (timer off / cap reached).
-static bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop) {
+bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop) {
     if (!g_prof_on) return false;   // (read without the lock: enabling mid-launch only loses that launch)
     std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof_on || g_prof_entries.size() >= g_prof_cap) return false;
@@ -319,19 +323,9 @@ static bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop) {
     return true;
 }
 
-// Every kernel of the path is launched through here.  With the timer on (and this launch sampled), the launch is bracketed
-// by two hipEventRecord on the same stream.  (hipExtLaunchKernelGGL's start / stop events would time the dispatch itself,
-// but a run of config 3 through it ended in a GPU memory access fault that the plain launch does not show; not pursued.)
-template <typename F, typename... Args>
-static void launch(int kind, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
-    hipEvent_t start = nullptr, stop = nullptr;
-    const bool timed = prof_take(kind, &start, &stop);
-    if (timed) (void)hipEventRecord(start, stream);
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
-    if (timed) (void)hipEventRecord(stop, stream);
-}
-
-static int check_launch() {
+// (launch<>() -- every kernel of the path is launched through it -- and allow_lds<>() live in sx_launch.hpp, shared with the
+// translation units of the register-resident rollout kernels.)
+int check_launch() {
     // SX_DEBUG_SYNC=1: wait for the launch and report an asynchronous failure at the call that caused it (diagnosis only)
     static const bool debug_sync = std::getenv("SX_DEBUG_SYNC") != nullptr;
     if (debug_sync) {
@@ -352,15 +346,14 @@ static int check_launch() {
 
 // Kernels that need more than 64 KB of dynamic LDS must be granted it once per (device, kernel); the grant is remembered,
 // so the hot loop's launches make no runtime call besides the launch itself.
-template <typename K>
-static int allow_lds(K kernel, size_t bytes) {
+int allow_lds_ptr(const void* kernel, size_t bytes) {
     if (bytes > kMaxLdsBytes) return SX_ERR_UNSUPPORTED;
     if (bytes > 64 * 1024) {
         static std::mutex mu;
         static std::map<std::pair<int, const void*>, size_t> granted;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const auto key = std::make_pair(dev, reinterpret_cast<const void*>(kernel));
+        const auto key = std::make_pair(dev, kernel);
         std::lock_guard<std::mutex> lock(mu);
         auto it = granted.find(key);
         if (it != granted.end() && it->second >= bytes) return SX_OK;
@@ -371,6 +364,21 @@ static int allow_lds(K kernel, size_t bytes) {
         granted[key] = bytes;
     }
     return SX_OK;
+}
+
+// compute units of the current device (the persistent grids are sized by it)
+int device_cus() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+    return n;
 }
 
 static bool predict_fits(int ns, int nu, int n_train, int n_pad, int ns_lds = -1) {
@@ -606,6 +614,20 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
                         (size_t)SX_TILE * rp.H * NU) * sizeof(double);
     const int tiles = (rp.P + SX_TILE - 1) / SX_TILE;
     if (all_at_once) {
+        // W resident in the register file (sx_rollout_rw.hpp) when it fits; SX_ROLLOUT=stream keeps the L2-streaming kernel
+        // for A/B runs
+        static const bool force_stream = std::getenv("SX_ROLLOUT") && std::strcmp(std::getenv("SX_ROLLOUT"), "stream") == 0;
+        if (!force_stream) {
+            auto gc4 = make_gp_const<NS, NU>(m, kRwWaves);
+#ifdef SX_STAMPS
+            RolloutPtrs rps = rp;
+            rps.stamps = g_stamp_host;
+            const int r = launch_rollout_rw<NS, NU>(gc4, rc, cc, rps, stream);
+#else
+            const int r = launch_rollout_rw<NS, NU>(gc4, rc, cc, rp, stream);
+#endif
+            if (r != SX_ERR_UNSUPPORTED) return r;
+        }
         if (int r = allow_lds(cem_rollout_kernel<NS, NU, false>, lds)) return r;
         launch(SX_PROF_ROLLOUT_FUSED, cem_rollout_kernel<NS, NU, false>, dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream,
                gc, gc.stage_tab, rc, cc, rp);
@@ -737,6 +759,7 @@ extern "C" {
 
 #ifdef SX_STAMPS
 int sx_debug_set_stamps(unsigned long long* dev_buf) {
+    sx::g_stamp_host = dev_buf;
     return hipMemcpyToSymbol(HIP_SYMBOL(sx::g_stamp_buf), &dev_buf, sizeof(dev_buf)) == hipSuccess ? SX_OK : SX_ERR_LAUNCH;
 }
 #endif

@@ -19,7 +19,7 @@ constexpr int kRolloutThreads = SX_ROLLOUT_THREADS;  // waves of the CU that own
 // ---------------------------------------------------------------------------------------------------------------
 #ifdef SX_STAMPS
 // Diagnostic build only (tools/phase_stamps.py): per-workgroup cycle sums of the three phases of a step.
-__device__ unsigned long long* g_stamp_buf = nullptr;
+static __device__ unsigned long long* g_stamp_buf = nullptr;   // (one per translation unit)
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -48,6 +48,9 @@ struct RolloutPtrs {
     int elite_k = 0;
     double* mean_out = nullptr;   // [E x H n_u] the refit, written by the first workgroup of each problem (may be null)
     double* std_out = nullptr;
+#ifdef SX_STAMPS
+    unsigned long long* stamps = nullptr;   // the register-resident kernels take the stamp buffer as an argument
+#endif
 };
 
 // BYOUT = false: Kstar of all outputs in LDS at once -- two barriers per step (the kernel measured throughout DESIGN.md).

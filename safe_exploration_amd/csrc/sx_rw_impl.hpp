@@ -1,0 +1,37 @@
+// Body of launch_rollout_rw<NS, NU>; included by sx_rw_ns*.hip, which instantiate it.
+#pragma once
+#include "sx_launch.hpp"
+#include "sx_rollout_rw.hpp"
+#include "sx_rw_launch.hpp"
+
+namespace sx {
+
+template <int NS, int NU, int NRB>
+static int rw_try(int nrb, const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& rc,
+                  const CostConst<SX_MAX_M, NS, NU>& cc, const RolloutPtrs& rp, hipStream_t stream) {
+    if constexpr (NRB == 0) {
+        return SX_ERR_UNSUPPORTED;
+    } else {
+        if (nrb != NRB) return rw_try<NS, NU, NRB - 1>(nrb, gc, rc, cc, rp, stream);
+        static_assert(rw_fits<NS, NRB>(), "rw_max_nrb promises more than the register budget holds");
+        const size_t lds = (gp_tile_lds_doubles(NS, NS + NU, gc.n_train, gc.n_pad, kRwWaves, NS) +
+                            (((size_t)SX_TILE * rp.H * NU + 1) & ~(size_t)1)) * sizeof(double) + sizeof(RwConst<NS, NU>);
+        if (int r = allow_lds(cem_rollout_rw_kernel<NS, NU, NRB>, lds)) return r;
+        const int tiles = rp.E * ((rp.P + SX_TILE - 1) / SX_TILE);
+        // one workgroup (4 waves x 512 registers) fills a compute unit: a persistent grid, W loaded once per workgroup
+        const int grid = tiles < device_cus() ? tiles : device_cus();
+        launch(SX_PROF_ROLLOUT_FUSED, cem_rollout_rw_kernel<NS, NU, NRB>, dim3(grid), dim3(kRwThreads), lds, stream, gc, rc, cc,
+               rp);
+        return check_launch();
+    }
+}
+
+template <int NS, int NU>
+int launch_rollout_rw(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& rc, const CostConst<SX_MAX_M, NS, NU>& cc,
+                      const RolloutPtrs& rp, hipStream_t stream) {
+    const int nrb = gc.n_pad >> 4;
+    if (nrb < 1 || nrb > rw_max_nrb(NS, NU)) return SX_ERR_UNSUPPORTED;
+    return rw_try<NS, NU, rw_max_nrb(NS, NU)>(nrb, gc, rc, cc, rp, stream);
+}
+
+}  // namespace sx

@@ -1,0 +1,25 @@
+// Launcher of the register-resident rollout kernels (sx_rollout_rw.hpp).  Its instantiations are compiled in translation
+// units of their own (sx_rw_ns{1..4}.hip: one per state dimension, built in parallel); sx_kernels.hip sees the declaration.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/sx_amd.h"
+#include "sx_gp.hpp"
+#include "sx_reach.hpp"
+#include "sx_rollout.hpp"
+
+namespace sx {
+
+constexpr int kRwWaves = 4;   // one wave per SIMD, 512 registers each
+
+// largest n_pad / 16 whose W fits the register budget next to the step's working set, i.e. that compiles without a
+// scratch spill (checked over all instantiations with tools/kernel_resources.py: (3, 1, 10), (4, 1, 7) and (4, 2, 7) spill)
+constexpr int rw_max_nrb(int ns, int nu) { return ns == 1 ? 18 : ns == 2 ? 13 : ns == 3 ? 9 : 6; }
+
+// Launches cem_rollout_rw_kernel<NS, NU, n_pad / 16> on `stream`; SX_ERR_UNSUPPORTED when the model is too large for the
+// register-resident form (the caller then takes cem_rollout_kernel).
+template <int NS, int NU>
+int launch_rollout_rw(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& rc, const CostConst<SX_MAX_M, NS, NU>& cc,
+                      const RolloutPtrs& rp, hipStream_t stream);
+
+}  // namespace sx

@@ -1,0 +1,7 @@
+// Register-resident rollout kernels (sx_rollout_rw.hpp) for state dimension 1: every n_pad / 16 that fits the register file.
+#include "sx_rw_impl.hpp"
+
+namespace sx {
+template int launch_rollout_rw<1, 1>(const GpConst<1, 2>&, const ReachConst<1, 1>&,
+                                      const CostConst<SX_MAX_M, 1, 1>&, const RolloutPtrs&, hipStream_t);
+}  // namespace sx

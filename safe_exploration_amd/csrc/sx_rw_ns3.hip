@@ -1,0 +1,7 @@
+// Register-resident rollout kernels (sx_rollout_rw.hpp) for state dimension 3: every n_pad / 16 that fits the register file.
+#include "sx_rw_impl.hpp"
+
+namespace sx {
+template int launch_rollout_rw<3, 1>(const GpConst<3, 4>&, const ReachConst<3, 1>&,
+                                      const CostConst<SX_MAX_M, 3, 1>&, const RolloutPtrs&, hipStream_t);
+}  // namespace sx

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/sx_amd.h"
+#include "sx_exp2_tab2048.hpp"
 #include "sx_gp.hpp"
 #include "sx_reach.hpp"
 #include "sx_refit.hpp"
@@ -39,13 +40,25 @@
 #ifndef SX_RW_LDSCONST
 #define SX_RW_LDSCONST 1   // finish() reads its constants from LDS instead of (spilled) SGPRs
 #endif
+#ifndef SX_RW_POLYLANES
+#define SX_RW_POLYLANES 1  // the state constraint's polytope rows on the four lane groups of wave 0 instead of a serial loop
+#endif
 #ifndef SX_RW_PF
 #define SX_RW_PF 2         // Kstar fragment pairs in flight ahead of the MFMAs that consume them (3 spills at n_pad = 208)
+#endif
+#ifndef SX_RW_DIET
+#define SX_RW_DIET 1       // Kstar phase with the expanded exponent, the 2048-entry table and no all-padding pairs (rw_kstar_phase)
 #endif
 #if SX_RW_PIPE
 #define SX_RW_KSTAR gp_kstar_phase_pipe
 #else
 #define SX_RW_KSTAR gp_kstar_phase
+#endif
+
+#if SX_RW_DIET
+#define RW_KSTAR_CALL(qb, qe) rw_kstar_phase(gc, kl, lds.kfrag, qb, qe, zq)
+#else
+#define RW_KSTAR_CALL(qb, qe) SX_RW_KSTAR(gc, lds, qb, qe, zq)
 #endif
 
 namespace sx {
@@ -212,6 +225,197 @@ __device__ __forceinline__ void rw_mfma_phase(const GpConst<NS, D>& gc, GpTileLd
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The Kstar phase of the register-resident kernel.  A lone wave per SIMD issues an f64 VALU instruction every ~5.8
+// cycles however many independent chains it has (tools/valu_probe3.hip: 2.7 ns; two waves per SIMD: 2.4 ns) and the
+// pipelined loop of gp_kstar_phase_pipe already runs at that rate, so the phase only gets shorter with FEWER
+// instructions per kernel value (85 per 2 rows x 2 outputs there):
+//   * expanded exponent.  With the rows centred, x' = x - xbar, z' = z - xbar, and in table units (ln 2 / 2048):
+//         y_d(k) = L_d + sum_j kk_dj (z'_j - x'_kj)^2 = [L_d + sum_j kk_dj z'_j^2] + [sum_j kk_dj x'_kj^2] + sum_j (-2 kk_dj z'_j) x'_kj
+//                =            zz_d (per thread and step)  +   c_kd (per row, once)   +  sum_j g_dj x'_kj
+//     one add and D fma per value instead of D (sub + mul) per row and D fma per value.  The centring keeps the
+//     cancellation harmless: the terms are O(radius^2 / l^2), not O(|x|^2 / l^2).
+//   * 2^(j/2048) table (16 KB of LDS, correctly rounded: sx_exp2_tab2048.hpp): |r| <= ln 2 / 4096, so a cubic suffices
+//     (truncation r^4/24 = 3.4e-17): two instructions less per value than the 256-entry table's quartic.
+//   * pairs of 8 rows that hold padding only (rows >= N) are not computed at all: their Kstar entries are zeroed once
+//     (the columns of W they meet are zero, they only have to be finite).
+// (The launcher hands this kernel k_nh_ils2 / k_log_os in units of ln 2 / 2048: 8 x GpConst's usual ones, exactly.)
+// 70 VALU instructions per 2 rows x 2 outputs.  The values differ from gp_kstar_phase's in the last bits (<= ~4e-16
+// relative for query points inside the data; the oracle comparisons allow 1e-9).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr double kExpScale2 = 2048.0 / 0.693147180559945309417232;   // 2048 / ln 2 = 8 kExpScale
+constexpr double kExpUnit2 = 0.693147180559945309417232 / 2048.0;
+
+template <int NS, int D>
+struct RwKstarLds {
+    double* rows;   // [n_pad][D + NS]: centred training inputs x' and c_kd (rows >= N: zeros)
+    double* tab;    // [2048] 2^(j/2048), then one NaN (the "table" of a NaN query point), one pad
+    double* xbar;   // [D] the centre (+ pad to an even count)
+    static __host__ __device__ size_t doubles(int n_pad) { return (size_t)n_pad * (D + NS) + (n_pad & 1) + kExpTab2 + 2 + ((D + 1) & ~1); }
+    __device__ void carve(double* base, int n_pad) {
+        rows = base;
+        tab = rows + (size_t)n_pad * (D + NS) + (n_pad & 1);
+        xbar = tab + kExpTab2 + 2;
+    }
+};
+
+// once per workgroup (the caller barriers afterwards): centre, rows, table, zeroed padding pairs of the Kstar buffer
+template <int NS, int D>
+__device__ __forceinline__ void rw_kstar_setup(const GpConst<NS, D>& gc, const RwKstarLds<NS, D>& kl, double* kfrag) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    // centre: mean of the first min(N, 64) rows -- any point inside the data cloud serves; every wave computes the same
+    double xb[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double v = lane < gc.n_train ? gc.x_train[lane * D + j] : 0.0;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        xb[j] = v / (double)(gc.n_train < 64 ? gc.n_train : 64);
+        if (tid == 0) kl.xbar[j] = xb[j];
+    }
+    for (int k = tid; k < gc.n_pad; k += blockDim.x) {
+        double xr[D], cc[NS];
+#pragma unroll
+        for (int d = 0; d < NS; ++d) cc[d] = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            xr[j] = k < gc.n_train ? gc.x_train[k * D + j] - xb[j] : 0.0;
+#pragma unroll
+            for (int d = 0; d < NS; ++d) cc[d] = fma(gc.k_nh_ils2[d * D + j], xr[j] * xr[j], cc[d]);
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) kl.rows[k * (D + NS) + j] = xr[j];
+#pragma unroll
+        for (int d = 0; d < NS; ++d) kl.rows[k * (D + NS) + D + d] = cc[d];
+    }
+    for (int i = tid; i < kExpTab2; i += blockDim.x) kl.tab[i] = kExp2Tab2048[i];
+    if (tid < 2) kl.tab[kExpTab2 + tid] = __builtin_nan("");
+    // pairs past the last training row are never written by the Kstar phase
+    const int first_pad = ((gc.n_train + 7) >> 3) * NS * 128;
+    for (int i = first_pad + tid; i < (gc.n_pad >> 3) * NS * 128; i += blockDim.x) kfrag[i] = 0.0;
+}
+
+template <int NS, int D>
+__device__ __forceinline__ void rw_kstar_phase(const GpConst<NS, D>& gc, const RwKstarLds<NS, D>& kl, double* kfrag,
+                                               int q_begin, int q_end, const double (&z)[D]) {
+    constexpr int M = 2 * NS, RS = D + NS;
+    const int n = q_end - q_begin;
+    if (n <= 0) return;
+    const int lane = (int)threadIdx.x & 63;
+    const int c = lane & 15;
+    // per thread and step: z' = z - xbar, zz_d, g_dj
+    double zz[NS], g[NS][D];
+    bool znan = false;
+    {
+        double zc[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            zc[j] = z[j] - kl.xbar[j];
+            znan = znan || (z[j] != z[j]);
+        }
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+            double a = gc.k_log_os[d];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double kz = gc.k_nh_ils2[d * D + j] * zc[j];
+                a = fma(kz, zc[j], a);
+                g[d][j] = -2.0 * kz;
+            }
+            zz[d] = a;
+        }
+    }
+    // a NaN query point must give NaN rows: its thread reads the one-entry NaN table
+    const lds_f64* etab = (const lds_f64*)kl.tab + (znan ? kExpTab2 : 0);
+    const int emask = znan ? 0 : kExpTab2 - 1;
+    const int k0 = 8 * q_begin + (lane >> 4);
+    const lds_f64* x = (const lds_f64*)kl.rows + k0 * RS;
+    lds_f64* f = (lds_f64*)kfrag + kfrag_index(NS, c, k0, 0);
+
+    struct Set {
+        double t[M], p[M];   // table entry (in flight after A1); r after A1, the polynomial after A2
+        int mi[M];
+    };
+    auto load_x = [&](double (&xx)[2 * RS]) {
+        asm volatile("" : "+v"(x));
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < RS; ++j) xx[h * RS + j] = x[h * 4 * RS + j];
+        x += 8 * RS;
+    };
+    auto stage_a1 = [&](const double (&xx)[2 * RS], Set& s) {
+        double yc[M], m[M];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int d = 0; d < NS; ++d) {
+                double a = xx[h * RS + D + d] + zz[d];
+#pragma unroll
+                for (int j = 0; j < D; ++j) a = fma(g[d][j], xx[h * RS + j], a);
+                yc[h * NS + d] = a;
+            }
+#pragma unroll
+        for (int i = 0; i < M; ++i) yc[i] = __builtin_fmax(yc[i], -800.0 * kExpScale2);
+#pragma unroll
+        for (int i = 0; i < M; ++i) m[i] = __builtin_rint(yc[i]);
+#pragma unroll
+        for (int i = 0; i < M; ++i) asm("v_cvt_i32_f64 %0, %1" : "=v"(s.mi[i]) : "v"(m[i]));
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.t[i] = etab[s.mi[i] & emask];
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = (yc[i] - m[i]) * kExpUnit2;   // r (the difference is exact)
+    };
+    auto stage_a2 = [&](Set& s) {
+        double r[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) r[i] = s.p[i];
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = fma(r[i], 1.66666666666666666667e-01, 0.5);
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = fma(s.p[i], r[i], 1.0);
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = s.p[i] * r[i];
+    };
+    auto stage_b = [&](const Set& s) {
+        asm volatile("" : "+v"(f));
+        double val[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) val[i] = ldexp(fma(s.t[i], s.p[i], s.t[i]), s.mi[i] >> 11);
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+            f[d * 128] = val[d];
+            f[d * 128 + 1] = val[NS + d];
+        }
+        f += NS * 128;
+    };
+    double xr[2 * RS];
+    Set s0, s1;
+    load_x(xr);           // trip 0
+    stage_a1(xr, s0);
+    load_x(xr);           // trip 1
+    stage_a2(s0);
+    auto body = [&](const Set& sold, Set& snew) {
+        stage_a1(xr, snew);
+        SX_PIN();
+        load_x(xr);
+        stage_b(sold);
+        SX_PIN();
+        stage_a2(snew);
+        SX_PIN();
+    };
+    const int n1 = n - 1;
+    for (int k = 0; k < (n1 >> 1); ++k) {
+        body(s0, s1);
+        body(s1, s0);
+    }
+    if (n1 & 1) {
+        body(s0, s1);
+        stage_b(s1);
+    } else {
+        stage_b(s0);
+    }
+}
+
 // What finish() needs of the kernel arguments, copied to LDS once per workgroup.  As kernel arguments these ~50 doubles
 // live in SGPRs, twice as many as a wave has: cem_rollout_kernel's finish() reads ~130 of them back from spill lanes
 // (v_readlane) per call, on the pipe the phase is bound by.  There two waves share a SIMD and the Kstar waves need the
@@ -253,6 +457,7 @@ __global__ __launch_bounds__(kRwThreads) __attribute__((amdgpu_waves_per_eu(1, 1
 void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostConst<SX_MAX_M, NS, NU> cc, RolloutPtrs rp) {
     constexpr int D = NS + NU;
     constexpr int S = NS + NS * NS;
+    constexpr int PQS = S + 3;   // a particle's row in LDS: p, Q (row-major), objective cost, constraint cost, status bits
     constexpr RwPlan<NS, NRB> plan{};
     constexpr int MAXP = plan.max_pairs();
     static_assert(MAXP <= kRwMaxPairs, "W does not fit the register budget");
@@ -278,10 +483,16 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
             cst->noise[tid] = gc.noise[tid];
         }
     }
+    // The tile's per-particle state between steps, [16][PQS]: (p, Q), the cost sums and the status bits.  It lives in LDS,
+    // not in registers: next to 368 registers of W the step loop has no room for values that idle through the Kstar and
+    // matrix phases (17 registers per lane in every wave, though only 16 lanes of wave 0 use them); finish() reads them
+    // at its start and writes them back, and the lanes that check the polytope rows read (p, Q) from here too.
+    double* const pq = reinterpret_cast<double*>(cst + 1);
     const RwConst<NS, NU>& fc = *cst;            // finish()'s view of the constants
     const ReachConst<NS, NU>& frc = cst->rc;
     const CostConst<SX_MAX_M, NS, NU>& fcc = cst->cc;
 #else
+    double* const pq = acts + (((size_t)SX_TILE * rp.H * NU + 1) & ~(size_t)1);
     const GpConst<NS, D>& fc = gc;
     const ReachConst<NS, NU>& frc = rc;
     const CostConst<SX_MAX_M, NS, NU>& fcc = cc;
@@ -294,13 +505,21 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
     // this wave's share of W: requested first, it travels while X, the exp table and the first tile's prologue are set up
     v2d wreg[MAXP];
     rw_load_w<NS, D, NRB>(gc, wave, lane, wreg);
+#if SX_RW_DIET
+    RwKstarLds<NS, D> kl;
+    kl.carve(pq + (((size_t)SX_TILE * PQS + 1) & ~(size_t)1), gc.n_pad);
+    rw_kstar_setup(gc, kl, lds.kfrag);
+    const int kstar_pairs = (gc.n_train + 7) >> 3;   // pairs of 8 rows with at least one training row
+#else
     gp_load_xs(gc, lds);
+    const int kstar_pairs = gc.n_pad >> 3;
+#endif
 
     const bool owner = tid < SX_TILE;
     // Kstar shares (pairs of fragments).  Step 0: all waves alike.  From step 1 on wave 0 runs finish() meanwhile.
     int q0_begin, q0_end, q_begin = 0, q_end = 0;
-    kstar_pair_range(gc.n_pad >> 3, wave, 1, nw, q0_begin, q0_end);
-    if (wave > 0) kstar_pair_range(gc.n_pad >> 3, wave - 1, 1, nw - 1, q_begin, q_end);
+    kstar_pair_range(kstar_pairs, wave, 1, nw, q0_begin, q0_end);
+    if (wave > 0) kstar_pair_range(kstar_pairs, wave - 1, 1, nw - 1, q_begin, q_end);
     double* const zs_base = lds.zs;
 
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
@@ -351,23 +570,24 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
             }
             acts[i] = a;
         }
-        // per-particle state lives in the registers of thread c (tid < 16) for the whole rollout
-        double p[NS], Q[NS][NS];
+        // per-particle state: LDS row of thread c (tid < 16)
         bool have_q = rp.q0 != nullptr;
-        double obj = 0.0, con = 0.0;
-        int st = 0;
+        double* const my = pq + (owner ? tid : 0) * PQS;
         if (owner) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                p[i] = rp.x0[(int64_t)e * NS + i];
+                my[i] = rp.x0[(int64_t)e * NS + i];
 #pragma unroll
-                for (int j = 0; j < NS; ++j) Q[i][j] = have_q ? rp.q0[((int64_t)e * NS + i) * NS + j] : 0.0;
+                for (int j = 0; j < NS; ++j) my[NS + i * NS + j] = have_q ? rp.q0[((int64_t)e * NS + i) * NS + j] : 0.0;
             }
+            my[S] = 0.0;       // objective cost
+            my[S + 1] = 0.0;   // constraint cost
+            reinterpret_cast<int*>(my + S + 2)[0] = 0;   // status bits
         }
         __syncthreads();
         if (owner) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = p[i];
+            for (int i = 0; i < NS; ++i) lds.zs[tid * D + i] = my[i];
 #pragma unroll
             for (int cidx = 0; cidx < NU; ++cidx) lds.zs[tid * D + NS + cidx] = acts[(tid * H + 0) * NU + cidx];
         }
@@ -387,6 +607,14 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
         };
         auto finish = [&](int t) {
             double z[D], u[NU], mean[NS], var[NS], jac[NS][D], p1[NS], Q1[NS][NS];
+            double p[NS], Q[NS][NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                p[i] = my[i];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) Q[i][j] = my[NS + i * NS + j];
+            }
+            double obj = my[S], con = my[S + 1];
 #pragma unroll
             for (int j = 0; j < NS; ++j) z[j] = p[j];
 #pragma unroll
@@ -418,16 +646,28 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
                     for (int cidx = 0; cidx < NU; ++cidx) zn[NS + cidx] = acts[(tid * H + t + 1) * NU + cidx];
                 }
             }
-            if (valid) st |= st_step;
+            if (valid && st_step) reinterpret_cast<int*>(my + S + 2)[0] |= st_step;
             obj += objective_cost<SX_MAX_M, NS, NU>(fcc, p1, var);
             bool uviol = false;
 #pragma unroll
             for (int cidx = 0; cidx < NU; ++cidx) uviol = uviol || (u[cidx] < fcc.u_min[cidx]) || (u[cidx] > fcc.u_max[cidx]);
             if (uviol) con += SX_ACTION_VIOLATION_COST;
+#if !SX_RW_POLYLANES
             if (fcc.con_mode == SX_CON_ALL_STATES || t == H - 1) {
                 if (polytope_violated<SX_MAX_M, NS>(fcc.h_mat, fcc.h_vec, fcc.m, 1.0, p1, Q1, nullptr))
                     con += SX_STATE_VIOLATION_COST;
             }
+#endif
+            // the new state (with SX_RW_POLYLANES the state constraint is checked from here by all four lane groups of the
+            // wave, one polytope row each: finish_polytope)
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                my[i] = p1[i];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) my[NS + i * NS + j] = Q1[i][j];
+            }
+            my[S] = obj;
+            my[S + 1] = con;
             const int64_t g = (int64_t)e * rp.P + c0 + tid;
             if (valid && rp.traj) {
                 double* tr = rp.traj + (g * H + t) * S;
@@ -442,13 +682,50 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
 #pragma unroll
                 for (int i = 0; i < NS; ++i) rp.sigma[(g * H + t) * NS + i] = var[i];
             }
+        };
+
+#if SX_RW_POLYLANES
+        // State constraint of step t (safempc_cem.py:102-132, gp_reachability_pytorch.py:184-231) on ALL 64 lanes of wave 0:
+        // lane l checks polytope rows (l >> 4) + 4 i of particle l & 15 -- d = h.p + sqrt(h.Q h) - b >= 0 violates (a NaN
+        // distance does not, as in the reference).  In finish() the rows were a serial loop on 16 lanes: m dependent sqrt
+        // chains, ~48 instructions each, on the wave the phase waits for; here the pendulum's 4 rows are ONE pass.  The
+        // verdicts of a particle's four lanes meet in a ballot (scalar unit).  Runs right after finish(t) on the same wave:
+        // the LDS hand-over of (p1, Q1) needs no barrier (a wave's LDS operations complete in order).
+        auto finish_polytope = [&](int t) {
+            if (!(fcc.con_mode == SX_CON_ALL_STATES || t == H - 1)) return;
+            const int c = lane & 15;
+            const double* o = pq + c * PQS;
+            double pp[NS], QQ[NS][NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                p[i] = p1[i];
+                pp[i] = o[i];
 #pragma unroll
-                for (int j = 0; j < NS; ++j) Q[i][j] = Q1[i][j];
+                for (int j = 0; j < NS; ++j) QQ[i][j] = o[NS + i * NS + j];
             }
+            bool viol = false;
+            const int m = fcc.m;
+            for (int r = lane >> 4; r < m; r += 4) {
+                double hc = 0.0, hq = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const double hi = fcc.h_mat[r * NS + i];
+                    hc += hi * pp[i];
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) sacc += QQ[i][j] * fcc.h_mat[r * NS + j];
+                    hq += hi * sacc;
+                }
+                const double dist = hc + sqrt(hq) - fcc.h_vec[r];
+                viol = viol || (dist >= 0.0);
+            }
+            unsigned long long bits = __ballot(viol);
+            bits |= bits >> 32;
+            bits |= bits >> 16;
+            if (owner && ((bits >> tid) & 1ull)) my[S + 1] += SX_STATE_VIOLATION_COST;
         };
+#else
+        auto finish_polytope = [&](int) {};
+#endif
 
 #ifdef SX_STAMPS
         unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0;
@@ -467,7 +744,7 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
                 if (t == 0) {
 #pragma unroll
                     for (int j = 0; j < D; ++j) zq[j] = zs_base[c * D + j];
-                    SX_RW_KSTAR(gc, lds, q0_begin, q0_end, zq);
+                    RW_KSTAR_CALL(q0_begin, q0_end);
                 } else {
                     double pc[NS];
                     next_centre(rc, c, zs_base + ((t - 1) & 1) * 16 * D + c * D, pc);
@@ -475,10 +752,11 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
                     for (int i = 0; i < NS; ++i) zq[i] = pc[i];
 #pragma unroll
                     for (int cidx = 0; cidx < NU; ++cidx) zq[NS + cidx] = acts[(c * H + t) * NU + cidx];
-                    SX_RW_KSTAR(gc, lds, q_begin, q_end, zq);
+                    RW_KSTAR_CALL(q_begin, q_end);
                 }
-            } else if (owner) {
-                finish(t - 1);
+            } else {
+                if (owner) finish(t - 1);
+                finish_polytope(t - 1);
             }
 #ifdef SX_STAMPS
             const unsigned long long t1 = stamp();
@@ -513,10 +791,12 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
         }
 #endif
         if (owner) finish(H - 1);
+        if (wave == 0) finish_polytope(H - 1);
         if (valid) {
             const int64_t g = (int64_t)e * rp.P + c0 + tid;
-            rp.obj_cost[g] = obj;
-            rp.con_cost[g] = con;
+            rp.obj_cost[g] = my[S];
+            rp.con_cost[g] = my[S + 1];
+            const int st = reinterpret_cast<const int*>(my + S + 2)[0];
             if (st) atomicOr(rp.status, st);
         }
         __syncthreads();   // the next tile's prologue reuses the Kstar buffer and the action table

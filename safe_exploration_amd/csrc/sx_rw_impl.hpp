@@ -15,7 +15,9 @@ static int rw_try(int nrb, const GpConst<NS, NS + NU>& gc, const ReachConst<NS, 
         if (nrb != NRB) return rw_try<NS, NU, NRB - 1>(nrb, gc, rc, cc, rp, stream);
         static_assert(rw_fits<NS, NRB>(), "rw_max_nrb promises more than the register budget holds");
         const size_t lds = (gp_tile_lds_doubles(NS, NS + NU, gc.n_train, gc.n_pad, kRwWaves, NS) +
-                            (((size_t)SX_TILE * rp.H * NU + 1) & ~(size_t)1)) * sizeof(double) + sizeof(RwConst<NS, NU>);
+                            (((size_t)SX_TILE * rp.H * NU + 1) & ~(size_t)1) + (((size_t)SX_TILE * (NS + NS * NS + 3) + 1) & ~(size_t)1) + RwKstarLds<NS, NS + NU>::doubles(gc.n_pad)) *
+                               sizeof(double) +
+                           sizeof(RwConst<NS, NU>);
         if (int r = allow_lds(cem_rollout_rw_kernel<NS, NU, NRB>, lds)) return r;
         const int tiles = rp.E * ((rp.P + SX_TILE - 1) / SX_TILE);
         // one workgroup (4 waves x 512 registers) fills a compute unit: a persistent grid, W loaded once per workgroup
@@ -31,7 +33,15 @@ int launch_rollout_rw(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& 
                       const RolloutPtrs& rp, hipStream_t stream) {
     const int nrb = gc.n_pad >> 4;
     if (nrb < 1 || nrb > rw_max_nrb(NS, NU)) return SX_ERR_UNSUPPORTED;
+#if SX_RW_DIET
+    // rw_kstar_phase's table is 2^(j/2048): the exponent constants in units of ln 2 / 2048 (a factor of 8: exact)
+    GpConst<NS, NS + NU> g8 = gc;
+    for (int i = 0; i < NS * (NS + NU); ++i) g8.k_nh_ils2[i] *= 8.0;
+    for (int d = 0; d < NS; ++d) g8.k_log_os[d] *= 8.0;
+    return rw_try<NS, NU, rw_max_nrb(NS, NU)>(nrb, g8, rc, cc, rp, stream);
+#else
     return rw_try<NS, NU, rw_max_nrb(NS, NU)>(nrb, gc, rc, cc, rp, stream);
+#endif
 }
 
 }  // namespace sx

@@ -13,8 +13,10 @@ namespace sx {
 constexpr int kRwWaves = 4;   // one wave per SIMD, 512 registers each
 
 // largest n_pad / 16 whose W fits the register budget next to the step's working set, i.e. that compiles without a
-// scratch spill (checked over all instantiations with tools/kernel_resources.py: (3, 1, 10), (4, 1, 7) and (4, 2, 7) spill)
-constexpr int rw_max_nrb(int ns, int nu) { return ns == 1 ? 18 : ns == 2 ? 13 : ns == 3 ? 9 : 6; }
+// scratch spill (checked over all instantiations with tools/kernel_resources.py after every change of the kernel)
+constexpr int rw_max_nrb(int ns, int nu) {
+    return ns == 1 ? 18 : ns == 2 ? (nu == 1 ? 13 : 12) : ns == 3 ? 8 : (nu == 1 ? 6 : 5);
+}
 
 // Launches cem_rollout_rw_kernel<NS, NU, n_pad / 16> on `stream`; SX_ERR_UNSUPPORTED when the model is too large for the
 // register-resident form (the caller then takes cem_rollout_kernel).

@@ -614,19 +614,26 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
                         (size_t)SX_TILE * rp.H * NU) * sizeof(double);
     const int tiles = (rp.P + SX_TILE - 1) / SX_TILE;
     if (all_at_once) {
-        // W resident in the register file (sx_rollout_rw.hpp) when it fits; SX_ROLLOUT=stream keeps the L2-streaming kernel
-        // for A/B runs
-        static const bool force_stream = std::getenv("SX_ROLLOUT") && std::strcmp(std::getenv("SX_ROLLOUT"), "stream") == 0;
-        if (!force_stream) {
-            auto gc4 = make_gp_const<NS, NU>(m, kRwWaves);
-#ifdef SX_STAMPS
+        // Three forms of the kernel: W partly resident on 8 waves (sx_rollout_rh.hpp: the default
+        // where it is instantiated, n_s <= 2), all of W in the registers of 4 waves (sx_rollout_rw.hpp: on request only --
+        // it does not beat the streaming kernel at one tile per compute unit), W streamed from L2 (cem_rollout_kernel: any
+        // size that fits the LDS).  SX_ROLLOUT=rh|rw|stream picks one for A/B runs; SX_ROLLOUT_STRICT forbids the silent
+        // fall-back to the streaming kernel, so that a run knows what it timed.
+        static const int form = [] {
+            const char* e = std::getenv("SX_ROLLOUT");
+            if (e && std::strcmp(e, "stream") == 0) return 0;
+            if (e && std::strcmp(e, "rw") == 0) return 1;
+            return 2;
+        }();
+        if (form != 0) {
+            static const bool strict = std::getenv("SX_ROLLOUT_STRICT") != nullptr;
             RolloutPtrs rps = rp;
+#ifdef SX_STAMPS
             rps.stamps = g_stamp_host;
-            const int r = launch_rollout_rw<NS, NU>(gc4, rc, cc, rps, stream);
-#else
-            const int r = launch_rollout_rw<NS, NU>(gc4, rc, cc, rp, stream);
 #endif
-            if (r != SX_ERR_UNSUPPORTED) return r;
+            const int r = form == 2 ? launch_rollout_rh<NS, NU>(make_gp_const<NS, NU>(m, 8), rc, cc, rps, stream)
+                                    : launch_rollout_rw<NS, NU>(make_gp_const<NS, NU>(m, kRwWaves), rc, cc, rps, stream);
+            if (r != SX_ERR_UNSUPPORTED || strict) return r;
         }
         if (int r = allow_lds(cem_rollout_kernel<NS, NU, false>, lds)) return r;
         launch(SX_PROF_ROLLOUT_FUSED, cem_rollout_kernel<NS, NU, false>, dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream,

@@ -234,9 +234,14 @@ __global__ __launch_bounds__(kCountThreads) void cem_rank_count_kernel(RankArgs 
     if (!ra.mean) return;
 
     // ---- 4. refit by the workgroup that delivers last ----
-    // The rows were stored at device scope; the barrier waits for every thread's stores to be acknowledged (vmcnt(0)), so
-    // one relaxed device-scope ticket per workgroup orders them: no __threadfence (an L2 write-back + invalidate per
-    // wave: 2048 of them took 30 us of this kernel's first version at P = 4096).
+    // The rows were stored at device scope (sc1: written through to the L2 all XCDs share).  Every wave first DRAINS its own
+    // stores -- s_waitcnt vmcnt(0): they are acknowledged, i.e. visible at device scope -- and only then joins the barrier
+    // behind which thread 0 takes the ticket.  (Round 2 relied on the barrier for that; gfx950's s_barrier does not wait for
+    // outstanding stores -- the built code was store, s_barrier, atomic with no wait in between -- so the last workgroup
+    // could in principle have read rows still in flight: ADVICE r2.)  The reader side pairs it with an acquire fence in the
+    // one workgroup that takes the last ticket.  No __threadfence per thread: an L2 write-back + invalidate per wave,
+    // 2048 of them, took 30 us of this kernel's first version at P = 4096.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) last_flag = (atomicInc(tickets + e, gridDim.x - 1) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(kCountThreads) void cem_rank_count_kernel(RankArgs 
     cs[6] = stamp();
 #endif
     if (!last_flag) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (one workgroup per problem gets here)
     const double* rows = ra.elite_rows + (long long)e * k * W;   // written by this launch: device-scope loads (sc1)
     constexpr int kKeep = 8;
     for (int c0 = 0; c0 < L; c0 += 256) {

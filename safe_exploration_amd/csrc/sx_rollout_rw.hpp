@@ -422,7 +422,7 @@ __device__ __forceinline__ void rw_kstar_phase(const GpConst<NS, D>& gc, const R
 // time anyway; here wave 0 is alone on its SIMD and finish() IS the phase's critical path, so every instruction counts:
 // from LDS a constant is one ds_read (no VALU slot), requested ahead of its use.
 template <int NS, int NU>
-struct RwConst {
+struct alignas(16) RwConst {
     ReachConst<NS, NU> rc;
     CostConst<SX_MAX_M, NS, NU> cc;
     double inv_ls2[NS * (NS + NU)];

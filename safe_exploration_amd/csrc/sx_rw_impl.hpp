@@ -1,6 +1,7 @@
 // Body of launch_rollout_rw<NS, NU>; included by sx_rw_ns*.hip, which instantiate it.
 #pragma once
 #include "sx_launch.hpp"
+#include "sx_rollout_rh.hpp"
 #include "sx_rollout_rw.hpp"
 #include "sx_rw_launch.hpp"
 
@@ -42,6 +43,35 @@ int launch_rollout_rw(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& 
 #else
     return rw_try<NS, NU, rw_max_nrb(NS, NU)>(nrb, gc, rc, cc, rp, stream);
 #endif
+}
+
+template <int NS, int NU, int NRB>
+static int rh_try(int nrb, const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& rc,
+                  const CostConst<SX_MAX_M, NS, NU>& cc, const RolloutPtrs& rp, hipStream_t stream) {
+    if constexpr (NRB == 0) {
+        return SX_ERR_UNSUPPORTED;
+    } else {
+        if (nrb != NRB) return rh_try<NS, NU, NRB - 1>(nrb, gc, rc, cc, rp, stream);
+        const size_t lds = rh_lds_doubles<NS, NU, NRB>(gc.n_train, gc.n_pad, rp.H) * sizeof(double) + sizeof(RwConst<NS, NU>);
+        if (int r = allow_lds(cem_rollout_rh_kernel<NS, NU, NRB>, lds)) return r;
+        const int tiles = rp.E * ((rp.P + SX_TILE - 1) / SX_TILE);
+        const int grid = tiles < device_cus() ? tiles : device_cus();
+        launch(SX_PROF_ROLLOUT_FUSED, cem_rollout_rh_kernel<NS, NU, NRB>, dim3(grid), dim3(kRhThreads), lds, stream, gc, rc, cc,
+               rp);
+        return check_launch();
+    }
+}
+
+template <int NS, int NU>
+int launch_rollout_rh(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& rc, const CostConst<SX_MAX_M, NS, NU>& cc,
+                      const RolloutPtrs& rp, hipStream_t stream) {
+    const int nrb = gc.n_pad >> 4;
+    if (nrb < 1 || nrb > rh_max_nrb(NS, NU)) return SX_ERR_UNSUPPORTED;
+    // rw_kstar_phase's table is 2^(j/2048): the exponent constants in units of ln 2 / 2048 (a factor of 8: exact)
+    GpConst<NS, NS + NU> g8 = gc;
+    for (int i = 0; i < NS * (NS + NU); ++i) g8.k_nh_ils2[i] *= 8.0;
+    for (int d = 0; d < NS; ++d) g8.k_log_os[d] *= 8.0;
+    return rh_try<NS, NU, rh_max_nrb(NS, NU)>(nrb, g8, rc, cc, rp, stream);
 }
 
 }  // namespace sx

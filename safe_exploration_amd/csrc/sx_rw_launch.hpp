@@ -24,4 +24,14 @@ template <int NS, int NU>
 int launch_rollout_rw(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& rc, const CostConst<SX_MAX_M, NS, NU>& cc,
                       const RolloutPtrs& rp, hipStream_t stream);
 
+// cem_rollout_rh_kernel (eight waves of 256 registers): instantiated where finish() and the Kstar phase leave room for the
+// resident pairs without a scratch spill -- n_s <= 2; at n_s >= 3 their working sets (Jacobi sweeps on 3 x 3 / 4 x 4
+// matrices, 2 n_s exponential chains) do not (tools/kernel_resources.py: (2, 2, 10) and every n_s >= 3 instantiation spill)
+constexpr int rh_max_nrb(int ns, int nu) { return ns == 1 ? 18 : ns == 2 ? (nu == 1 ? 13 : 8) : 0; }
+
+// The same for cem_rollout_rh_kernel (sx_rollout_rh.hpp: eight waves, W partly resident).
+template <int NS, int NU>
+int launch_rollout_rh(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& rc, const CostConst<SX_MAX_M, NS, NU>& cc,
+                      const RolloutPtrs& rp, hipStream_t stream);
+
 }  // namespace sx

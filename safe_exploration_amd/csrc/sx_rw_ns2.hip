@@ -1,9 +1,13 @@
-// Register-resident rollout kernels (sx_rollout_rw.hpp) for state dimension 2: every n_pad / 16 that fits the register file.
+// Register-resident rollout kernels (sx_rollout_rw.hpp, sx_rollout_rh.hpp) for state dimension 2: every n_pad / 16 that fits.
 #include "sx_rw_impl.hpp"
 
 namespace sx {
 template int launch_rollout_rw<2, 1>(const GpConst<2, 3>&, const ReachConst<2, 1>&,
                                       const CostConst<SX_MAX_M, 2, 1>&, const RolloutPtrs&, hipStream_t);
+template int launch_rollout_rh<2, 1>(const GpConst<2, 3>&, const ReachConst<2, 1>&,
+                                      const CostConst<SX_MAX_M, 2, 1>&, const RolloutPtrs&, hipStream_t);
 template int launch_rollout_rw<2, 2>(const GpConst<2, 4>&, const ReachConst<2, 2>&,
+                                      const CostConst<SX_MAX_M, 2, 2>&, const RolloutPtrs&, hipStream_t);
+template int launch_rollout_rh<2, 2>(const GpConst<2, 4>&, const ReachConst<2, 2>&,
                                       const CostConst<SX_MAX_M, 2, 2>&, const RolloutPtrs&, hipStream_t);
 }  // namespace sx

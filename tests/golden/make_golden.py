@@ -8,6 +8,12 @@ What runs from the reference, unmodified (imported from /root/reference, never c
     safe_exploration/gp_reachability.py           onestep_reachability (the reference's own numpy twin, as a cross-check)
     safe_exploration/utils.py                     compute_remainder_overapproximations_pytorch
     safe_exploration/utils_ellipsoid.py           sum_two_ellipsoids_pytorch, ellipsoid_from_rectangle_pytorch
+    safe_exploration/ssm_cem/gal_concrete_dropout.py   _Model.forward (:95-105, with _ConcreteDropout :28-66), _heteroscedastic_loss
+                                                  (:119-121), GalConcreteDropoutSSM.predict_raw / predict_with_jacobians
+                                                  (:166-196) -- with torch.rand_like replaying RECORDED uniforms that are
+                                                  constant over the batch rows, so that a forward pass is one frozen
+                                                  ensemble member (dropout_gal.npz)
+    safe_exploration/ssm_cem/dropout_ssm_cem.py   McDropoutSSM._gaussian_log_likelihood (:163-173; static)
 
 To import those files, modules that are not installed here (casadi, gpytorch, hessian) are replaced by NAME-ONLY
 placeholders (no arithmetic; none of the functions above call into them) and ``torch.eig`` -- removed from current
@@ -50,6 +56,7 @@ def _install_placeholders():
     for sub, names in subs.items():
         setattr(g, sub, mod('gpytorch.' + sub, **{n: _Name for n in names}))
     mod('hessian', hessian=None)
+    mod('bnn', BDropout=_Name, CDropout=_Name, bayesian_model=None)   # (dropout_ssm_cem.py:4,7; only its static loss is run)
     # torch.eig survives only as a stub that raises; give it back its old (values [n x 2], None) return
     torch.eig = lambda A, eigenvectors=False: (torch.view_as_real(torch.linalg.eigvals(A)).to(A.dtype), None)
 
@@ -251,5 +258,92 @@ def main():
     print('wrote helpers')
 
 
+def dropout_main():
+    """dropout_gal.npz: the reference's concrete-dropout network as a frozen ensemble (missing #1)."""
+    torch.set_default_dtype(torch.double)
+    _install_placeholders()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import types as _types
+
+    import safe_exploration.ssm_cem.gal_concrete_dropout as gal
+    from safe_exploration.ssm_cem.dropout_ssm_cem import McDropoutSSM as RefMcDropout
+
+    rng = np.random.default_rng(2024)
+    n_s, n_u, hidden, S, B = 2, 1, [8, 6], 5, 7
+    d_in = n_s + n_u
+    wr, dr = 0.7 ** 2 / 40.0, 2.0 / 40.0          # length_scale^2 / N, 2 / N (:205-207) for N = 40
+    torch.manual_seed(7)
+    model = gal._Model(d_in, n_s, hidden, wr, dr)
+    # four different dropout probabilities (the constructor starts all of them at 0.1)
+    probs = np.array([0.08, 0.15, 0.22, 0.3])
+    with torch.no_grad():
+        for mod_, pr in zip((model.conc_drop1, model.conc_drop2, model.conc_drop_mu, model.conc_drop_logvar), probs):
+            mod_.p_logit.fill_(float(np.log(pr) - np.log(1 - pr)))
+    widths = [d_in, hidden[0], hidden[1], hidden[1]]           # what the four concrete-dropout layers see
+    uniforms = [rng.uniform(0.02, 0.98, size=(S, w)) for w in widths]
+
+    # torch.rand_like, as gal_concrete_dropout.py:61 calls it: the recorded uniforms of member `member`, the same in every
+    # batch row; the four layers are visited in the order conc_drop1, conc_drop2, conc_drop_mu, conc_drop_logvar (:98-103)
+    state = {'member': 0, 'layer': 0}
+    real_rand_like = torch.rand_like
+
+    def replay(x, *a, **k):
+        u = torch.tensor(uniforms[state['layer']][state['member']])
+        assert x.shape[-1] == u.numel()
+        state['layer'] += 1
+        if state['layer'] == 4:
+            state['layer'] = 0
+            state['member'] = (state['member'] + 1) % S
+        return u.expand_as(x).clone()
+
+    x = torch.tensor(rng.uniform(-0.6, 0.6, size=(B, d_in)))
+    y = torch.tensor(rng.normal(0, 0.3, size=(B, n_s)))
+    out = {'n_s': n_s, 'n_u': n_u, 'hidden': np.array(hidden), 'probs': probs, 'weight_regularizer': wr,
+           'dropout_regularizer': dr, 'x': x.numpy(), 'y': y.numpy(),
+           'u_in': uniforms[0], 'u_h1': uniforms[1], 'u_h2_mu': uniforms[2], 'u_h2_logvar': uniforms[3]}
+    for name, lin in (('1', model.linear1), ('2', model.linear2), ('mu', model.linear3_mu), ('logvar', model.linear3_logvar)):
+        out['W' + name] = lin.weight.detach().numpy().copy()
+        out['b' + name] = lin.bias.detach().numpy().copy()
+    torch.rand_like = replay
+    try:
+        means, logvars, regs, losses = [], [], [], []
+        for s in range(S):
+            state.update(member=s, layer=0)
+            mean, log_var, reg = model(x)                                    # _Model.forward :95-105
+            means.append(mean.detach().numpy().copy())
+            logvars.append(log_var.detach().numpy().copy())
+            regs.append(float(reg))
+            losses.append(float(gal._heteroscedastic_loss(y, mean, log_var)))   # :119-121
+        out.update(member_mean=np.stack(means), member_logvar=np.stack(logvars), regularization=np.array(regs),
+                   heteroscedastic_loss=np.array(losses))
+        conf = _types.SimpleNamespace(mc_dropout_on_input=True, mc_dropout_type='concrete', mc_dropout_predict_std=True,
+                                      mc_dropout_num_samples=S, mc_dropout_training_iterations=0,
+                                      mc_dropout_hidden_features=hidden, mc_dropout_lengthscale=0.7, device='cpu')
+        ssm = gal.GalConcreteDropoutSSM(conf, n_s, n_u)
+        ssm._model = model
+        state.update(member=0, layer=0)
+        pm, pv = ssm.predict_raw(x)                                          # :185-196: mean, var(0) over the S passes
+        state.update(member=0, layer=0)
+        pm2, pv2, jac = ssm.predict_with_jacobians(x[:, :n_s].clone(), x[:, n_s:].clone())   # :166-177
+        out.update(pred_mean=pm.detach().numpy(), pred_var=pv.detach().numpy(), pred_jac=jac.detach().numpy())
+        assert np.allclose(pm2.detach().numpy(), out['pred_mean']) and np.allclose(pv2.detach().numpy(), out['pred_var'])
+    finally:
+        torch.rand_like = real_rand_like
+    # McDropoutSSM's static Gaussian log likelihood (dropout_ssm_cem.py:163-173), with and without predicted log stds
+    t = torch.tensor(rng.normal(size=(B, n_s)))
+    pmn = torch.tensor(rng.normal(size=(B, n_s)))
+    pls = torch.tensor(rng.normal(0, 0.4, size=(B, n_s)))
+    out.update(ll_targets=t.numpy(), ll_means=pmn.numpy(), ll_log_stds=pls.numpy(),
+               ll_with_std=RefMcDropout._gaussian_log_likelihood(t, pmn, pls).numpy(),
+               ll_without_std=RefMcDropout._gaussian_log_likelihood(t, pmn, None).numpy())
+    np.savez(os.path.join(HERE, 'dropout_gal.npz'), **out)
+    print('wrote dropout_gal')
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'dropout':
+        dropout_main()
+    else:
+        main()
+        dropout_main()

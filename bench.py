@@ -18,6 +18,7 @@ and resident in HBM before the timed region.  Rank 0 prints ONE JSON line; a non
 have raised ValueError on this workload) is an error, not a throughput.
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -49,12 +50,14 @@ def n_pad_of(n_train, d_in):
     return (n_train + 1 + d_in + 15) // 16 * 16          # csrc/sx_gp.hpp gp_n_pad
 
 
-def mfma_per_launch_fused(n_s, n_train, d_in, tiles, horizon, waves=8):
-    """v_mfma_f64_16x16x4 instructions one cem_rollout_kernel launch executes: per 16-particle tile and step, every
-    output's triangular product (row-block rb = 2 (rb + 1) fragment pairs = 4 (rb + 1) MFMAs) plus one column-total MFMA
-    per output and wave.  (rocprofv3's SQ_INSTS_MFMA agrees to the instruction: profiles/*pmc*.json.)"""
+def mfma_per_launch_fused(n_s, n_train, d_in, tiles, horizon, totals=16):
+    """v_mfma_f64_16x16x4 instructions one launch of the fused rollout kernel executes: per 16-particle tile and step, every
+    output's triangular product (row-block rb = 2 (rb + 1) fragment pairs = 4 (rb + 1) MFMAs) plus `totals` column-total
+    MFMAs (one per output and wave that owns row-blocks of it: waves x n_s in cem_rollout_kernel, one per wave in the
+    resident forms at n_s <= the wave-group count).  (rocprofv3's SQ_INSTS_MFMA agrees to the instruction:
+    profiles/*pmc*.json.)"""
     nrb = n_pad_of(n_train, d_in) // 16
-    per_tile_step = n_s * 2 * nrb * (nrb + 1) + waves * n_s
+    per_tile_step = n_s * 2 * nrb * (nrb + 1) + totals
     return per_tile_step * tiles * horizon
 
 
@@ -96,18 +99,42 @@ def mlp_flops_per_particle_step(widths, d_in, n_s, n_out, members):
     return 2 * members * (fwd + n_s * bwd)
 
 
-def PROFILE_STRIDE(cfg):
-    return 1 if cfg == 4 else 16
+def PROFILE_STRIDE(cfg, launches=None):
+    """Every n-th launch of a kernel class is bracketed by HIP events: 16 costs < 1 % (every launch 7 %), but at least ~50
+    launches must be timed -- the driver's `--steps 20` is 160 rollout launches."""
+    if cfg == 4:
+        return 1
+    if launches is None:
+        return 16
+    return max(1, min(16, launches // 50))
 
 
 def pmc_summary(cfg):
-    """The committed rocprofv3 --pmc summary for this config (profiles/r02_pmc_cfg<N>.json), or None.  bench.py cannot
-    collect PMC counters itself; the numbers are only reported for the workload they were collected on."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', f'r02_pmc_cfg{cfg}.json')) as f:
-            return json.load(f)
-    except Exception:
-        return None
+    """The committed rocprofv3 --pmc summary for this config (profiles/r03_pmc_cfg<N>.json, else round 2's), or None.
+    bench.py cannot collect PMC counters itself; the numbers are only reported for the workload AND kernel they were
+    collected on."""
+    for rnd in ('r03', 'r02'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_cfg{cfg}.json')) as f:
+                return json.load(f)
+        except Exception:
+            continue
+    return None
+
+
+FORM_KERNEL = {0: 'cem_rollout_kernel', 1: 'cem_rollout_rw_kernel', 2: 'cem_rollout_rh_kernel', 3: 'cem_rollout_kernel',
+               4: 'trmm_reduce_kernel'}
+# column-total MFMAs per tile and step: cem_rollout_kernel 8 waves x n_s; the resident forms one per (wave, output) pair
+# that owns row-blocks -- with whole wave groups per output (n_s divides the wave count) that is one per wave
+def total_mfmas(form, n_s):
+    waves = {1: 4, 2: 8}.get(form)
+    if waves is None:
+        return 8 * n_s
+    return waves if waves % n_s == 0 else waves * n_s     # (upper bound for the ungrouped plans: n_s = 3)
+
+
+# what a pair of HIP events adds to the launch it brackets (the 7.8 us ranking kernel reads 10.6 us through events)
+EVENT_OVERHEAD_US = 2.8
 
 
 def cpu_baseline(w, budget_s=12.0):
@@ -167,7 +194,7 @@ def cpu_baseline_mlp(w, ssm, budget_s=10.0):
                       f'(oracle/gp.py DropoutEnsemble + oracle/cem.py), float64, {dt:.1f} s'}
 
 
-def roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, cfg, mlp=None):
+def roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, cfg, mlp=None, form=0):
     """The `roofline` object of the JSON line, for the kernel that took the largest share of the timed region."""
     dominant = max(kernels, key=lambda k: kernels[k][0])
     avg_s = kernels[dominant][0] / kernels[dominant][1] * 1e-3
@@ -183,18 +210,20 @@ def roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, cfg, mlp=None
         n_mfma = mfma_per_launch_trmm(spec.n_s, n_train, d_in, E * P)
     else:
         units = E * P * H                            # one launch = the whole rollout
-        n_mfma = mfma_per_launch_fused(spec.n_s, n_train, d_in, E * ((P + 15) // 16), H)
+        n_mfma = mfma_per_launch_fused(spec.n_s, n_train, d_in, E * ((P + 15) // 16), H, total_mfmas(form, spec.n_s))
     executed = n_mfma * MFMA_FLOPS / avg_s / 1e12
     algorithmic = flops_unit * units / avg_s / 1e12
     frac = executed / F64_MATRIX_PEAK_TFLOPS
     assert frac <= 1.0, f'roofline fraction {frac} > 1: the flop count or the timer is wrong'
+    is_mlp = dominant == 'cem_rollout_mlp_kernel'
+    kernel_name = dominant_name if is_mlp else (FORM_KERNEL.get(form, dominant) if dominant == 'cem_rollout_kernel' else dominant)
     pmc = pmc_summary(cfg)
     traffic = None
     if pmc and pmc.get('workload') == f'cfg{cfg} N_train={n_train} H={H} P={P} E={E}':
-        traffic = pmc.get('hbm_traffic_bytes_per_launch', {}).get(dominant)
-    is_mlp = dominant == 'cem_rollout_mlp_kernel'
+        by_kernel = pmc.get('hbm_traffic_bytes_per_launch', {})
+        traffic = by_kernel.get(kernel_name, by_kernel.get(dominant) if kernel_name == dominant else None)
     return {'bound': 'mfma', 'achieved': executed, 'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': frac, 'kernel': dominant_name if is_mlp else dominant,
+            'frac': frac, 'kernel': kernel_name,
             'avg_launch_us': avg_s * 1e6, 'launches_timed': kernels[dominant][1],
             'flops': 'EXECUTED: v_mfma_f64_16x16x4 instructions per launch x 2048; analytic count, equal to SQ_INSTS_MFMA ('
                      + ('csrc/sx_mlp_mfma.hpp, profiles/r02_pmc_mlp.json)' if is_mlp else 'the triangular form)'),
@@ -207,7 +236,7 @@ def roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, cfg, mlp=None
                                       '(N^2), so algorithmic_tflops may exceed the peak'),
             'traffic': traffic,
             'traffic_unit': 'B/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950; '
-                            'profiles/r02_pmc_cfg*.json)',
+                            'profiles/r03_pmc_cfg*.json)',
             'hbm_gb_per_s': (traffic / avg_s / 1e9) if traffic else None}
 
 
@@ -244,6 +273,9 @@ def main():
     ap.add_argument('--particles', type=int, default=0, help='per GPU; 0 = the workload\'s own')
     ap.add_argument('--horizon', type=int, default=0)
     ap.add_argument('--n-train', type=int, default=0)
+    ap.add_argument('--ard', action='store_true',
+                    help='config 2 with distinct per-output ARD length-scales / outputscales / noise (what a fitted model '
+                         'looks like; the plain config has the same hyper-parameters for both outputs)')
     ap.add_argument('--iters', type=int, default=0, help='CEM iterations per solve (reference default 8)')
     ap.add_argument('--elites', type=int, default=0, help='0 = 10 %% of the per-GPU particle count')
     ap.add_argument('--ssm', default='gp', choices=['gp', 'mc_dropout'],
@@ -303,7 +335,7 @@ def main():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         group, force_exchange = dist.group.WORLD, True
 
-    w = problems.baseline_workload(args.config, n_gpus=world, n_train=args.n_train or None)
+    w = problems.baseline_workload(args.config, n_gpus=world, n_train=args.n_train or None, ard=args.ard)
     spec = w.spec
     P = args.particles or w.particles
     H = args.horizon or w.horizon
@@ -352,7 +384,7 @@ def main():
             # HIP events on every 16th launch of each kernel (every launch of the large-N path, whose kernels run for
             # milliseconds): timing every 130 us launch costs the solve ~7 % (measured), every 4th 2.6 % (1.121 against
             # 1.092 ms with the timer off), every 16th < 1 % -- 50 timed launches per kernel in the default run
-            _lib.check(lib.sx_profile_stride(PROFILE_STRIDE(w.cfg)), 'sx_profile_stride')
+            _lib.check(lib.sx_profile_stride(PROFILE_STRIDE(w.cfg, steps * iters)), 'sx_profile_stride')
             _lib.check(lib.sx_profile_enable(max(4096, steps * iters * (3 * H + 4))), 'sx_profile_enable')
 
     if w.cfg == 5:
@@ -392,10 +424,13 @@ def main():
             mpc.exchange_events = []
         barrier()
         t0 = time.perf_counter()
+        statuses = []
         for _ in range(steps):
             best, ok, _, status = mpc.solve(x0)
+            statuses.append(status)          # (a view into the solver's status pool: no launch, no synchronisation)
         barrier()
         elapsed = time.perf_counter() - t0
+        status = torch.cat([t.reshape(-1) for t in statuses])   # EVERY timed solve's status word is checked below
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -405,6 +440,25 @@ def main():
     if not args.no_kernel_timer:
         kernels = _lib.profile_collect()             # {kernel: (total ms, launches)}, HIP events on the launch stream
         _lib.check(lib.sx_profile_disable(), 'sx_profile_disable')
+    # The synchronous call a control loop makes (episode_runner.py:216-221 times solver.get_action): state in, one
+    # device->host hand-off with status, flag and actions out -- timed after the kernel timer is off, on a bounded number of
+    # solves; `value` stays the enqueue-only throughput of the region above.
+    sync_ms = None
+    if w.cfg != 5 and status_word == 0:
+        n_s = spec.n_s
+        flat = torch.cat((x0[:1], torch.zeros((1, n_s * n_s), dtype=torch.float64, device=dev)), dim=1)
+        n_sync = max(1, min(steps, 200))
+        mpc.get_actions(flat)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sync):
+            mpc.get_actions(flat)
+        barrier()
+        sync_ms = (time.perf_counter() - t1) / n_sync * 1e3
+        if world > 1:
+            t = torch.tensor([sync_ms], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            sync_ms = float(t.item())
     exchange_us = None
     if mpc.exchange_events:
         xs = [a.elapsed_time(b) for a, b in mpc.exchange_events]
@@ -425,13 +479,23 @@ def main():
             particle_steps = (P * world if w.sharded else P * episodes_total) * H * iters * steps
             flops_unit = algorithmic_flops_per_particle_step(spec.n_s, n_train, d_in) if mlp is None else \
                 mlp_flops_per_particle_step(mlp['hidden'], d_in, spec.n_s, spec.n_s, mlp['members'])
-            stride = PROFILE_STRIDE(w.cfg)       # every stride-th launch of a kernel is timed (start_timer)
-            per_kernel = {k: {'avg_launch_us': ms / n * 1e3, 'launches_timed': n,
-                              'share_of_step': min(1.0, ms * stride / (elapsed * 1e3))}
-                          for k, (ms, n) in kernels.items()}
+            stride = PROFILE_STRIDE(w.cfg, steps * iters)   # every stride-th launch of a kernel is timed (start_timer)
+            form = int(lib.sx_cem_rollout_form(ctypes.byref(ssm.device_model), H)) if mlp is None else 0
+            # shares of the step NET of what the event pair adds to a launch it brackets (raw, the 8 us ranking kernel alone
+            # reads 35 % high and the shares summed to 1.017 in round 2); the sum is capped at 1
+            per_kernel = {}
+            for k, (ms, n) in kernels.items():
+                net_us = max(ms / n * 1e3 - EVENT_OVERHEAD_US, 0.0)
+                per_kernel[FORM_KERNEL.get(form, k) if k == 'cem_rollout_kernel' else k] = {
+                    'avg_launch_us': ms / n * 1e3, 'launches_timed': n, 'net_of_event_pair_us': net_us,
+                    'share_of_step': net_us * 1e-3 * n * stride / (elapsed * 1e3)}
+            total_share = sum(v['share_of_step'] for v in per_kernel.values())
+            if total_share > 1.0:
+                for v in per_kernel.values():
+                    v['share_of_step'] /= total_share
             roofline = None
             if kernels:
-                roofline = roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, w.cfg, mlp)
+                roofline = roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, w.cfg, mlp, form)
             out = {
                 'metric': 'cem_particle_step_evals_per_s', 'value': particle_steps / elapsed, 'unit': 'particle-steps/s',
                 'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
@@ -453,6 +517,9 @@ def main():
                                                 f'(episode_runner.do_rollout_batch)'),
                            'backend': args.backend if world > 1 else None},
                 'mpc_solves_per_s': steps * episodes_total / elapsed,
+                'sync_solve_ms': sync_ms,
+                'get_action_solves_per_s': (1e3 / sync_ms) if sync_ms else None,
+                'timed_solves_status_checked': int(status.numel()),
                 'particle_rollouts_per_s': particle_steps / H / elapsed,
                 'device_status': status_word, 'solution_found': bool(ok[0].item()),
                 'exchange_us': exchange_us,

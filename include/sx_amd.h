@@ -283,6 +283,21 @@ int sx_cem_rollout_elites(const sx_gp_model* model, const sx_env* env, int E, in
  * < 0 = bad arguments. */
 int64_t sx_cem_rollout_workspace_bytes(const sx_gp_model* model, int E, int P, int H);
 
+/* Which kernel sx_cem_rollout / sx_cem_rollout_elites launch for this model and horizon (no launch, no device access):
+ *   SX_FORM_RH      cem_rollout_rh_kernel: 8 waves, the GP's triangular factors partly resident (registers / LDS / L2)
+ *   SX_FORM_RW      cem_rollout_rw_kernel: 4 waves, the factors in the register file
+ *   SX_FORM_STREAM  cem_rollout_kernel: the factors streamed from L2, Kstar of all outputs in LDS
+ *   SX_FORM_BYOUT   cem_rollout_kernel, one output's Kstar in LDS at a time
+ *   SX_FORM_BIG     the three-launch-per-step path (Kstar in HBM)
+ * or < 0 for bad arguments.  Reporting only (bench.py names the kernel it timed); the choice itself is the library's.
+ * No counterpart in the reference. */
+#define SX_FORM_STREAM 0
+#define SX_FORM_RW 1
+#define SX_FORM_RH 2
+#define SX_FORM_BYOUT 3
+#define SX_FORM_BIG 4
+int sx_cem_rollout_form(const sx_gp_model* model, int H);
+
 /* The ONE device -> host hand-off of a solve, packed by one launch: out dev double [G + E + 1 + E*row_len] =
  *   [status words of the G ranks | best_ok[E] | 1.0 if any of the `q_count` doubles at `q_block` is non-zero | best [E x row_len]]
  * (q_block may be NULL: the flag is 0).  The caller copies `out` to the host once and reads everything from it.

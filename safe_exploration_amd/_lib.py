@@ -93,6 +93,7 @@ SIGNATURES = {
     'sx_profile_collect': (c_int, [c_int, POINTER(c_double), POINTER(c_int64)]),
     'sx_profile_disable': (c_int, []),
     'sx_cem_rank_counts': (c_int, [c_int, c_int]),
+    'sx_cem_rollout_form': (c_int, [POINTER(SxGpModel), c_int]),
     'sx_cem_pack_result': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'sx_cem_rank_refit': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64]
                           + [c_void_p] * 7),

@@ -771,7 +771,7 @@ int sx_debug_set_stamps(unsigned long long* dev_buf) {
 }
 #endif
 
-const char* sx_version(void) { return "sxamd 0.2 gfx950"; }
+const char* sx_version(void) { return "sxamd 0.3 gfx950"; }
 
 int sx_profile_enable(int max_launches) {
     if (max_launches <= 0) return SX_ERR_ARG;
@@ -1080,6 +1080,21 @@ int64_t sx_cem_rollout_workspace_bytes(const sx_gp_model* model, int E, int P, i
     if (model->n_s > 1 && sx::fused_fits(model->n_s, model->n_u, model->n_train, model->n_pad, H, 1)) return 0;
     return sx::big_ws_layout(nullptr, model->n_s, model->n_s + model->n_u, model->n_pad, (int64_t)E * P).total *
            (int64_t)sizeof(double);
+}
+
+int sx_cem_rollout_form(const sx_gp_model* model, int H) {
+    if (!model || H <= 0) return -1;
+    const int ns = model->n_s, nu = model->n_u;
+    if (!sx::fused_fits(ns, nu, model->n_train, model->n_pad, H))
+        return (ns > 1 && sx::fused_fits(ns, nu, model->n_train, model->n_pad, H, 1)) ? SX_FORM_BYOUT : SX_FORM_BIG;
+    const char* e = std::getenv("SX_ROLLOUT");
+    if (e && std::strcmp(e, "stream") == 0) return SX_FORM_STREAM;
+    const bool want_rw = e && std::strcmp(e, "rw") == 0;
+#define CALL(NS, NU) \
+    (want_rw ? (sx::rollout_rw_applies<NS, NU>(model->n_train, model->n_pad, H) ? SX_FORM_RW : SX_FORM_STREAM) \
+             : (sx::rollout_rh_applies<NS, NU>(model->n_train, model->n_pad, H) ? SX_FORM_RH : SX_FORM_STREAM))
+    SX_DISPATCH(ns, nu, CALL);
+#undef CALL
 }
 
 int sx_cem_rollout(const sx_gp_model* model, const sx_env* env, int E, int P, int H, const double* x0, const double* q0,

@@ -74,4 +74,31 @@ int launch_rollout_rh(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& 
     return rh_try<NS, NU, rh_max_nrb(NS, NU)>(nrb, g8, rc, cc, rp, stream);
 }
 
+template <int NS, int NU, int NRB>
+static size_t rh_lds_bytes_of(int nrb, int n_train, int n_pad, int H) {
+    if constexpr (NRB == 0) {
+        return ~(size_t)0;
+    } else {
+        if (nrb != NRB) return rh_lds_bytes_of<NS, NU, NRB - 1>(nrb, n_train, n_pad, H);
+        return rh_lds_doubles<NS, NU, NRB>(n_train, n_pad, H) * sizeof(double) + sizeof(RwConst<NS, NU>);
+    }
+}
+
+template <int NS, int NU>
+bool rollout_rh_applies(int n_train, int n_pad, int H) {
+    const int nrb = n_pad >> 4;
+    if (nrb < 1 || nrb > rh_max_nrb(NS, NU)) return false;
+    return rh_lds_bytes_of<NS, NU, rh_max_nrb(NS, NU)>(nrb, n_train, n_pad, H) <= kMaxLdsBytes;
+}
+
+template <int NS, int NU>
+bool rollout_rw_applies(int n_train, int n_pad, int H) {
+    const int nrb = n_pad >> 4;
+    if (nrb < 1 || nrb > rw_max_nrb(NS, NU)) return false;
+    const size_t lds = (gp_tile_lds_doubles(NS, NS + NU, n_train, n_pad, kRwWaves, NS) + (((size_t)SX_TILE * H * NU + 1) & ~(size_t)1) +
+                        (((size_t)SX_TILE * (NS + NS * NS + 3) + 1) & ~(size_t)1) + RwKstarLds<NS, NS + NU>::doubles(n_pad)) *
+                           sizeof(double) + sizeof(RwConst<NS, NU>);
+    return lds <= kMaxLdsBytes;
+}
+
 }  // namespace sx

@@ -34,4 +34,10 @@ template <int NS, int NU>
 int launch_rollout_rh(const GpConst<NS, NS + NU>& gc, const ReachConst<NS, NU>& rc, const CostConst<SX_MAX_M, NS, NU>& cc,
                       const RolloutPtrs& rp, hipStream_t stream);
 
+// Would launch_rollout_rh / launch_rollout_rw take this model (an instantiation exists and its LDS fits)?  No launch.
+template <int NS, int NU>
+bool rollout_rh_applies(int n_train, int n_pad, int H);
+template <int NS, int NU>
+bool rollout_rw_applies(int n_train, int n_pad, int H);
+
 }  // namespace sx

@@ -10,4 +10,8 @@ template int launch_rollout_rw<4, 2>(const GpConst<4, 6>&, const ReachConst<4, 2
                                       const CostConst<SX_MAX_M, 4, 2>&, const RolloutPtrs&, hipStream_t);
 template int launch_rollout_rh<4, 2>(const GpConst<4, 6>&, const ReachConst<4, 2>&,
                                       const CostConst<SX_MAX_M, 4, 2>&, const RolloutPtrs&, hipStream_t);
+template bool rollout_rh_applies<4, 1>(int, int, int);
+template bool rollout_rw_applies<4, 1>(int, int, int);
+template bool rollout_rh_applies<4, 2>(int, int, int);
+template bool rollout_rw_applies<4, 2>(int, int, int);
 }  // namespace sx

@@ -185,10 +185,21 @@ class FeatureGP:
         return out
 
 
+def concrete_dropout_mask(u, p, eps=1e-7, temperature=0.1):
+    """Multiplier of concrete dropout for uniform noise u and drop probability p (reference
+    ssm_cem/gal_concrete_dropout.py:49-66): x * (1 - sigmoid((logit(p) + logit(u)) / temperature)) / (1 - p), the logits with
+    the reference's eps.  Pinned to the reference by tests/golden/dropout_gal.npz."""
+    u = np.asarray(u, dtype=np.float64)
+    logit = np.log(p + eps) - np.log(1 - p + eps) + np.log(u + eps) - np.log(1 - u + eps)
+    return (1.0 - 1.0 / (1.0 + np.exp(-logit / temperature))) / (1.0 - p)
+
+
 class DropoutEnsemble:
-    """MC-dropout state-space model with FROZEN masks (reference ssm_cem/dropout_ssm_cem.py, gal_concrete_dropout.py;
-    the `bnn` package is absent and the reference's masks come from torch's RNG: values PARITY UNPINNED): an ensemble of S
-    thinned ReLU networks,
+    """MC-dropout state-space model with FROZEN masks (reference ssm_cem/dropout_ssm_cem.py, gal_concrete_dropout.py): an
+    ensemble of S thinned ReLU networks.  PINNED for the concrete-dropout network: with the reference's own forward pass
+    replaying recorded noise (one frozen member per pass), per-member outputs, predict_raw's mean / var(0) and the mean
+    Jacobian agree with this class to 1e-12 (tests/golden/dropout_gal.npz, tests/test_oracle_golden.py).  The `bnn`-based
+    McDropoutSSM stays unpinned (the package is absent).
         a_0 = m_0^s * z,   a_l = relu(W_l a_{l-1} + b_l) * m_l^s,   out^s = W_out a_L + b_out,
     mean / unbiased variance over the members of the first n_s outputs (dropout_ssm_cem.py:100-112: `preds.mean(dim=0)`,
     `preds.var(dim=0)`), analytic Jacobian of the mean.  With `predict_std` the outputs n_s .. 2 n_s - 1 are log standard

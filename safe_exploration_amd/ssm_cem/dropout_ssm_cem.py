@@ -138,11 +138,17 @@ class McDropoutSSM(CemSSM):
         return net
 
     # ---- the frozen ensemble: what the device kernels see ------------------------------------------------------
-    def _freeze(self) -> None:
-        """Draws the members' masks (seeded) and lays weights and masks out for sx_mlp_predict / sx_cem_rollout_mlp."""
+    def _freeze(self, masks=None) -> None:
+        """Draws the members' masks (seeded) and lays weights and masks out for sx_mlp_predict / sx_cem_rollout_mlp.
+        `masks`: the members' multipliers given instead of drawn ([S x width] per masked layer: input, hidden ...) -- how the
+        golden test puts the reference's recorded noise behind the device kernels."""
         net = self._model
         with torch.no_grad():
-            masks = net.draw_masks((self._num_mc_samples,), generator=self._gen)
+            if masks is None:
+                masks = net.draw_masks((self._num_mc_samples,), generator=self._gen)
+            else:
+                masks = [torch.as_tensor(m, dtype=torch.float64, device=self._device) for m in masks]
+                assert [tuple(m.shape) for m in masks] == [(self._num_mc_samples, w) for w in net.sizes]
             mask_buf = torch.cat(masks, dim=1).contiguous()                                   # [S x sum widths]
             parts = []
             for lin in list(net.linears) + [net.out]:
@@ -205,13 +211,16 @@ class McDropoutSSM(CemSSM):
         reg = 1e-2 * self._model.regularization(n_data)
         if self._type == 'fixed':
             return torch.nn.functional.mse_loss(means, targets) + reg
-        deltas = means - targets
-        if self._predict_std:
-            log_std = output[:, self.num_states:]
-            ll = -((deltas / log_std.exp()) ** 2).sum(-1) * 0.5 - log_std.sum(-1) - math.log(2 * math.pi) * 0.5
-        else:
-            ll = -(deltas ** 2).sum(-1) * 0.5
+        ll = self._gaussian_log_likelihood(targets, means, output[:, self.num_states:] if self._predict_std else None)
         return (-ll + reg).mean()
+
+    @staticmethod
+    def _gaussian_log_likelihood(targets: Tensor, pred_means: Tensor, pred_log_stds: Optional[Tensor]) -> Tensor:
+        """Reference dropout_ssm_cem.py:163-173 (pinned by tests/golden/dropout_gal.npz)."""
+        deltas = pred_means - targets
+        if pred_log_stds is not None:
+            return -((deltas / pred_log_stds.exp()) ** 2).sum(-1) * 0.5 - pred_log_stds.sum(-1) - math.log(2 * math.pi) * 0.5
+        return -(deltas ** 2).sum(-1) * 0.5
 
     def _train_model(self, x_train: Tensor, y_train: Tensor) -> None:
         if self._reinitialize_on_train:

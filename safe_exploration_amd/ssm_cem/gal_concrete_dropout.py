@@ -42,25 +42,35 @@ class _GalNet(nn.Module):
         return torch.sigmoid(self.p_logit)
 
     @staticmethod
-    def _mask(shape, p, dev, generator=None) -> Tensor:
-        u = torch.rand(shape, dtype=torch.float64, device=dev, generator=generator)
+    def mask_from_uniform(u: Tensor, p) -> Tensor:
+        """The multiplier concrete dropout applies for uniform noise u and drop probability p (reference :49-66):
+        (1 - sigmoid((logit p + logit u) / 0.1)) / (1 - p).  Pinned to the reference by tests/golden/dropout_gal.npz."""
         drop = torch.sigmoid((torch.log(p + _EPS) - torch.log(1 - p + _EPS) + torch.log(u + _EPS) - torch.log(1 - u + _EPS))
                              / _TEMPERATURE)
         return (1 - drop) / (1 - p)
+
+    @classmethod
+    def _mask(cls, shape, p, dev, generator=None) -> Tensor:
+        return cls.mask_from_uniform(torch.rand(shape, dtype=torch.float64, device=dev, generator=generator), p)
 
     def draw_masks(self, shape_prefix, generator=None) -> List[Tensor]:
         """Multipliers of the input, of h1 and of h2 as the MEAN head sees it."""
         p, dev = self.rates(), self.p_logit.device
         return [self._mask(shape_prefix + (w,), p[i], dev, generator) for i, w in enumerate(self.sizes)]
 
-    def forward_train(self, x: Tensor, weight_regularizer: float, dropout_regularizer: float, generator=None):
+    def forward_train(self, x: Tensor, weight_regularizer: float, dropout_regularizer: float, generator=None, uniforms=None):
+        """One stochastic pass (reference _Model.forward, :95-105) -> (mean, log_var, regularisation).  `uniforms`: the four
+        layers' noise [n x width] (or broadcastable) instead of fresh draws -- how the golden test replays the reference."""
         p, dev = self.rates(), x.device
         n = x.size(0)
-        a0 = x * self._mask((n, self.sizes[0]), p[0], dev, generator)
+        widths = [self.sizes[0], self.sizes[1], self.sizes[2], self.sizes[2]]
+        m = [self.mask_from_uniform(uniforms[i], p[i]) if uniforms is not None else self._mask((n, widths[i]), p[i], dev, generator)
+             for i in range(4)]
+        a0 = x * m[0]
         h1 = torch.relu(self.linear1(a0))
-        h2 = torch.relu(self.linear2(h1 * self._mask((n, self.sizes[1]), p[1], dev, generator)))
-        mean = self.linear3_mu(h2 * self._mask((n, self.sizes[2]), p[2], dev, generator))
-        log_var = self.linear3_logvar(h2 * self._mask((n, self.sizes[2]), p[3], dev, generator))
+        h2 = torch.relu(self.linear2(h1 * m[1]))
+        mean = self.linear3_mu(h2 * m[2])
+        log_var = self.linear3_logvar(h2 * m[3])
         reg = torch.zeros((), dtype=torch.float64, device=dev)
         dims = [self.sizes[0], self.sizes[1], self.sizes[2], self.sizes[2]]
         for i, lin in enumerate((self.linear1, self.linear2, self.linear3_mu, self.linear3_logvar)):

@@ -170,6 +170,32 @@ def test_gal_concrete_dropout_ssm():
         McDropoutSSM(conf(mc_dropout_type='fixed', mc_dropout_predict_std=True), 2, 1)
 
 
+def test_gal_device_ensemble_vs_the_reference_fixture(golden_dir):
+    """tests/golden/dropout_gal.npz: weights, dropout probabilities, recorded noise and the outputs of the REFERENCE's
+    GalConcreteDropoutSSM.predict_raw / predict_with_jacobians when torch.rand_like replays that noise (one frozen member per
+    pass; tests/golden/make_golden.py).  The device ensemble on the same weights, with its members' masks computed from the
+    same noise, must return the reference's mean, var(0) and mean Jacobian."""
+    from safe_exploration_amd.ssm_cem.gal_concrete_dropout import GalConcreteDropoutSSM, _GalNet
+    g = np.load(os.path.join(golden_dir, 'dropout_gal.npz'))
+    S = g['u_in'].shape[0]
+    c = conf(mc_dropout_type='concrete', mc_dropout_predict_std=True, mc_dropout_on_input=True,
+             mc_dropout_hidden_features=[int(h) for h in g['hidden']], mc_dropout_num_samples=S)
+    ssm = GalConcreteDropoutSSM(c, 2, 1)
+    net = ssm._model
+    with torch.no_grad():
+        for lin, name in ((net.linear1, '1'), (net.linear2, '2'), (net.linear3_mu, 'mu'), (net.linear3_logvar, 'logvar')):
+            lin.weight.copy_(T(g['W' + name]))
+            lin.bias.copy_(T(g['b' + name]))
+        net.p_logit.copy_(T(np.log(g['probs']) - np.log(1 - g['probs'])))
+    p = net.rates()
+    ssm._freeze(masks=[_GalNet.mask_from_uniform(T(g[k]), p[i]) for i, k in enumerate(('u_in', 'u_h1', 'u_h2_mu'))])
+    x = g['x']
+    m, v, j = ssm.predict_with_jacobians(T(x[:, :2]), T(x[:, 2:]))
+    np.testing.assert_allclose(m.cpu().numpy(), g['pred_mean'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(v.cpu().numpy(), g['pred_var'], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(j.cpu().numpy(), g['pred_jac'], rtol=1e-10, atol=1e-12)
+
+
 def test_matrix_core_kernel_equals_lane_kernel_at_the_default_size(mlp_path):
     """64 x 64, 30 members (experiments/sacred_helper.py:100-102), config 2's particle count: the two kernels against each
     other, rollout costs and trajectories (different summation orders: tolerance, not bits)."""

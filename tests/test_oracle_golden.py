@@ -286,3 +286,64 @@ def test_oracle_rank_orders_numbers_and_puts_nan_last():
     np.testing.assert_array_equal(ocem.rank(con, obj, 7), [6, 2, 0, 1, 5, 4, 3])
     obj2 = np.array([np.nan, np.inf, 0.0, -0.0, -np.inf, 2.0, 2.0])
     np.testing.assert_array_equal(ocem.rank(np.zeros(7), obj2, 7), [4, 2, 3, 5, 6, 1, 0])
+
+
+# ---- the concrete-dropout network, pinned to the reference (tests/golden/dropout_gal.npz; VERDICT r2 missing #1) ----
+def _gal_fixture(golden_dir):
+    return np.load(os.path.join(golden_dir, 'dropout_gal.npz'))
+
+
+def _gal_masks(g):
+    from oracle.gp import concrete_dropout_mask
+    p = g['probs']
+    return [concrete_dropout_mask(g[k], p[i]) for i, k in enumerate(('u_in', 'u_h1', 'u_h2_mu', 'u_h2_logvar'))]
+
+
+def test_dropout_oracle_reproduces_the_reference_gal_network(golden_dir):
+    """The fixture holds what the REFERENCE's _Model.forward / predict_raw / predict_with_jacobians return when
+    torch.rand_like replays recorded uniforms that are constant over the batch (one frozen member per pass):
+    oracle.gp.DropoutEnsemble on the same weights and the masks oracle.gp.concrete_dropout_mask derives from the same
+    uniforms must give the same numbers -- per member, and as the ensemble (mean, unbiased variance, mean Jacobian)."""
+    from oracle.gp import DropoutEnsemble
+    g = _gal_fixture(golden_dir)
+    m_in, m_h1, m_mu, m_lv = _gal_masks(g)
+    x, S = g['x'], g['u_in'].shape[0]
+    hidden = [(g['W1'], g['b1']), (g['W2'], g['b2'])]
+    for s in range(S):
+        one_mu = DropoutEnsemble(hidden + [(g['Wmu'], g['bmu'])], np.concatenate((m_in[s], m_h1[s], m_mu[s]))[None], 2)
+        np.testing.assert_allclose(one_mu.predict(x, False)[0], g['member_mean'][s], rtol=1e-12, atol=1e-14)
+        one_lv = DropoutEnsemble(hidden + [(g['Wlogvar'], g['blogvar'])], np.concatenate((m_in[s], m_h1[s], m_lv[s]))[None], 2)
+        np.testing.assert_allclose(one_lv.predict(x, False)[0], g['member_logvar'][s], rtol=1e-12, atol=1e-14)
+    ens = DropoutEnsemble(hidden + [(g['Wmu'], g['bmu'])], np.concatenate((m_in, m_h1, m_mu), axis=1), 2)
+    mean, var, jac = ens.predict(x)
+    np.testing.assert_allclose(mean, g['pred_mean'], rtol=1e-12, atol=1e-14)      # predict_raw :185-196
+    np.testing.assert_allclose(var, g['pred_var'], rtol=1e-10, atol=1e-16)        # means.var(0): unbiased
+    np.testing.assert_allclose(jac, g['pred_jac'], rtol=1e-11, atol=1e-13)        # compute_jacobian_fast over predict_raw
+
+
+def test_gal_training_pass_and_losses_reproduce_the_reference(golden_dir):
+    """The product's training network (_GalNet.forward_train) on the fixture's weights and noise: mean, log variance and the
+    regularisation term of the reference's _Model.forward (:95-105, :28-47), its heteroscedastic loss (:119-121), and
+    McDropoutSSM's Gaussian log likelihood (dropout_ssm_cem.py:163-173)."""
+    import torch
+    from safe_exploration_amd.ssm_cem.dropout_ssm_cem import McDropoutSSM
+    from safe_exploration_amd.ssm_cem.gal_concrete_dropout import _GalNet
+    g = _gal_fixture(golden_dir)
+    net = _GalNet(3, 2, [int(h) for h in g['hidden']]).to(torch.float64)
+    with torch.no_grad():
+        for lin, name in ((net.linear1, '1'), (net.linear2, '2'), (net.linear3_mu, 'mu'), (net.linear3_logvar, 'logvar')):
+            lin.weight.copy_(torch.tensor(g['W' + name]))
+            lin.bias.copy_(torch.tensor(g['b' + name]))
+        net.p_logit.copy_(torch.tensor(np.log(g['probs']) - np.log(1 - g['probs'])))
+    x, y = torch.tensor(g['x']), torch.tensor(g['y'])
+    for s in range(g['u_in'].shape[0]):
+        u = [torch.tensor(g[k][s]).expand(x.size(0), -1) for k in ('u_in', 'u_h1', 'u_h2_mu', 'u_h2_logvar')]
+        mean, log_var, reg = net.forward_train(x, float(g['weight_regularizer']), float(g['dropout_regularizer']), uniforms=u)
+        np.testing.assert_allclose(mean.detach().numpy(), g['member_mean'][s], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(log_var.detach().numpy(), g['member_logvar'][s], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(float(reg.detach()), g['regularization'][s], rtol=1e-12)
+        loss = torch.mean(torch.sum(torch.exp(-log_var) * (y - mean) ** 2 + log_var, 1), 0)
+        np.testing.assert_allclose(float(loss.detach()), g['heteroscedastic_loss'][s], rtol=1e-12)
+    t, m, ls = (torch.tensor(g[k]) for k in ('ll_targets', 'll_means', 'll_log_stds'))
+    np.testing.assert_allclose(McDropoutSSM._gaussian_log_likelihood(t, m, ls).numpy(), g['ll_with_std'], rtol=1e-13)
+    np.testing.assert_allclose(McDropoutSSM._gaussian_log_likelihood(t, m, None).numpy(), g['ll_without_std'], rtol=1e-13)

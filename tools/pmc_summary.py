@@ -20,7 +20,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = ['cem_rollout_kernel', 'cem_rank_kernel', 'cem_rank_count_kernel', 'trmm_reduce_kernel', 'kstar_big_kernel', 'step_big_kernel']
+KERNELS = ['cem_rollout_rh_kernel', 'cem_rollout_rw_kernel', 'cem_rollout_kernel', 'cem_rank_kernel', 'cem_rank_count_kernel', 'trmm_reduce_kernel', 'kstar_big_kernel', 'step_big_kernel']
 
 
 def main():

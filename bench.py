@@ -459,10 +459,17 @@ def main():
             t = torch.tensor([sync_ms], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             sync_ms = float(t.item())
-    exchange_us = None
+    exchange_us = exchange_parts = None
     if mpc.exchange_events:
-        xs = [a.elapsed_time(b) for a, b in mpc.exchange_events]
-        exchange_us = sum(xs) / len(xs) * 1e3
+        # per sharded iteration (every 16th is bracketed): local ranking | collective | global ranking; exchange_us = the two
+        # multi-GPU parts together, as in round 2
+        n = len(mpc.exchange_events)
+        part = lambda i: sum(ev[i].elapsed_time(ev[i + 1]) for ev in mpc.exchange_events) / n * 1e3
+        exchange_parts = {'local_rank_us': part(0), 'collective_us': part(1), 'global_rank_us': part(2),
+                          'iterations_timed': n,
+                          'collective': ('ncclAllGather on the compute stream (own RCCL communicator, distributed.RcclComm)'
+                                         if getattr(mpc, '_comm', None) is not None else 'torch.distributed ' + str(args.backend))}
+        exchange_us = exchange_parts['collective_us'] + exchange_parts['global_rank_us']
     if world > 1 and not w.sharded:
         sw = torch.tensor([status_word], dtype=torch.int32, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(sw, op=dist.ReduceOp.MAX, group=group)    # (bit-OR would do; any non-zero word fails the run)
@@ -523,6 +530,7 @@ def main():
                 'particle_rollouts_per_s': particle_steps / H / elapsed,
                 'device_status': status_word, 'solution_found': bool(ok[0].item()),
                 'exchange_us': exchange_us,
+                'exchange_breakdown': exchange_parts,
                 'roofline': roofline,
                 'kernels': per_kernel,
             }

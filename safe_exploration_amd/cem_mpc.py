@@ -304,9 +304,15 @@ class FusedCemMpc:
                              f'too large for it (limit {min(self._local_rollouts // chunks, RANK_MAX_CANDIDATES // chunks)})')
         self._device = torch.device(device if device is not None else 'cuda:0')
         self._init_std = self._init_std.to(self._device)
+        # the iteration's collective on the compute stream (our own RCCL communicator) where the group is an nccl one
+        self._comm = (distributed.RcclComm(process_group, self._device)
+                      if self._sharded and distributed.RcclComm.wanted(process_group, self._device) else None)
         self._gen = torch.Generator(device=self._device)
         self._gen.manual_seed(distributed.rank_seed(seed, self._rank))
         self.last_status = 0
+        # a CemSSM that only offers the predict_* surface (JunkDimensionsSSM over a HIP-backed model) is always rolled out
+        # step by step: sx_gp_predict through the wrapper + sx_onestep_reach per step, the reference's own call pattern
+        self._always_stepwise = getattr(ssm, 'kernel_family', None) == 'stepwise'
         self.stepwise_fallbacks = 0     # solves repeated through the step-by-step path (see _solve_checked)
         self._last_noise = self._last_actions = None
         self._objective_hook = None
@@ -380,11 +386,11 @@ class FusedCemMpc:
         padding rows never change, so the object is built once and kept -- four small launches per solve otherwise.  Several
         problems (all-reduce over zero padding): fresh, zeroed buffers per solve."""
         if episodes != 1:
-            return distributed.EliteExchange(self._num_iterations, episodes, k, row_len, self._group, dev)
+            return distributed.EliteExchange(self._num_iterations, episodes, k, row_len, self._group, dev, comm=self._comm)
         key = (k, row_len, str(dev))
         cache = self.__dict__.setdefault('_xch_cache', {})
         if key not in cache:
-            cache[key] = distributed.EliteExchange(self._num_iterations, 1, k, row_len, self._group, dev)
+            cache[key] = distributed.EliteExchange(self._num_iterations, 1, k, row_len, self._group, dev, comm=self._comm)
         return cache[key]
 
     def _next_noise(self, episodes: int) -> Tensor:
@@ -441,6 +447,7 @@ class FusedCemMpc:
         history: List[Rollouts] = []
         out = None
         xch = None
+        stepwise = stepwise or self._always_stepwise
         if noise is None and 'sample_noise' not in vars(self):
             # one generator launch for the whole solve instead of one per iteration (a test that patches sample_noise
             # on the instance still gets its per-iteration calls)
@@ -490,6 +497,11 @@ class FusedCemMpc:
                 k = self._local_elites
                 if xch is None:
                     xch = self._exchange(E, k, L, dev)
+                timed = self.exchange_events is not None and self._exchanges_seen % self.exchange_event_stride == 0
+                self._exchanges_seen += 1
+                if timed:   # four marks: before the local ranking | before the collective | after it | after the global ranking
+                    xev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    xev[0].record(torch.cuda.current_stream(dev))
                 if E == 1:
                     # the local elite rows go straight into this rank's slot: no copy between the kernel and the collective
                     cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], k, want_refit=False,
@@ -498,14 +510,13 @@ class FusedCemMpc:
                     local = cem_rank_refit_any(r['con_cost'], r['obj_cost'], r['actions'], k, want_rows=True, want_refit=False)
                     xch.local_slot(it).copy_(local['elite_rows'])
                 last = it == self._num_iterations - 1
-                timed = self.exchange_events is not None and self._exchanges_seen % self.exchange_event_stride == 0
-                self._exchanges_seen += 1
                 if timed:
-                    xev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                    xev[0].record(torch.cuda.current_stream(dev))
+                    xev[1].record(torch.cuda.current_stream(dev))
                 # the ONE collective of the iteration; on the last one the status words of all ranks ride along
                 # (every rollout of this solve has been enqueued by then)
                 cand, words = xch.exchange(it, status if last else None)
+                if timed:
+                    xev[2].record(torch.cuda.current_stream(dev))
                 if last:
                     status = words
                 flat = cand.reshape(-1)
@@ -513,7 +524,7 @@ class FusedCemMpc:
                                      act_stride=2 + L, row_len=L, num_candidates=xch.candidates, num_problems=E,
                                      want_rows=in_prologue, want_refit=not in_prologue)
                 if timed:
-                    xev[1].record(torch.cuda.current_stream(dev))
+                    xev[3].record(torch.cuda.current_stream(dev))
                     self.exchange_events.append(xev)
             if in_prologue:
                 rows = out['elite_rows']

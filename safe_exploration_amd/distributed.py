@@ -6,11 +6,96 @@ ranks' top-k rows [k x (2 + H n_u)] (several problems at once: an all-reduce(sum
 message is a few hundred KB at most -- latency-bound on xGMI -- so nothing larger is ever moved.  After it every rank holds
 the same bytes and redundantly picks the global top-k and refits: no second collective, results bit-identical across ranks.
 """
+import ctypes
+import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
 from torch import Tensor
+
+
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [('internal', ctypes.c_char * 128)]
+
+
+class RcclComm:
+    """An RCCL communicator of our own, driven through ctypes from the librccl.so torch ships, so that the ONE collective of
+    a CEM iteration is enqueued on the COMPUTE stream like any kernel: rollout -> local ranking -> all-gather -> global
+    ranking run back to back on one stream.  torch's NCCL process group runs collectives on a stream of its own and brackets
+    each with two cross-stream event waits and a Python `Work` object: with ONE rank (no inter-GPU latency at all) that
+    plumbing was a third of the sharded path's fixed cost of 15 us per iteration.
+
+    Created collectively (every rank of `group` constructs it): rank 0's ncclUniqueId travels over the existing process
+    group (any backend), then ncclCommInitRank.  One device per rank, as RCCL requires.  SX_RCCL_DIRECT=0 turns the direct
+    path off (FusedCemMpc then uses torch.distributed's collectives)."""
+    FLOAT64, SUM = 8, 0     # ncclFloat64, ncclSum (nccl.h)
+
+    _lib = None
+
+    @classmethod
+    def library(cls):
+        if cls._lib is None:
+            path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+            lib = ctypes.CDLL(path)     # (already mapped by torch: the same library instance)
+            lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
+            lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+            lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p]
+            lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+            lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            lib.ncclGetErrorString.argtypes = [ctypes.c_int]
+            lib.ncclGetErrorString.restype = ctypes.c_char_p
+            for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllGather, lib.ncclAllReduce, lib.ncclCommDestroy):
+                f.restype = ctypes.c_int
+            cls._lib = lib
+        return cls._lib
+
+    @classmethod
+    def wanted(cls, group, device) -> bool:
+        """Direct RCCL where the group's backend is nccl (one device per rank) and it is not switched off."""
+        if group is None or os.environ.get('SX_RCCL_DIRECT', '1') == '0' or torch.device(device).type != 'cuda':
+            return False
+        try:
+            return 'nccl' in str(dist.get_backend(group))
+        except Exception:   # noqa: BLE001
+            return False
+
+    def __init__(self, group, device):
+        lib = self.library()
+        self.device = torch.device(device)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = _NcclUniqueId()
+        if self.rank == 0:
+            self._check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+        payload = [bytes(uid.internal)] if self.rank == 0 else [None]
+        if self.world > 1:
+            dist.broadcast_object_list(payload, src=dist.get_global_rank(group, 0), group=group)
+        ctypes.memmove(ctypes.byref(uid), payload[0], 128)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        self._finalizer = weakref.finalize(self, lib.ncclCommDestroy, self._comm)
+
+    def _check(self, code: int, what: str) -> None:
+        if code != 0:
+            raise RuntimeError(f'{what} failed: {self.library().ncclGetErrorString(code).decode()}')
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def all_gather(self, send: Tensor, recv: Tensor) -> None:
+        """recv [world x send.numel()] <- every rank's send, enqueued on the current stream (float64, contiguous)."""
+        assert send.is_contiguous() and recv.is_contiguous() and recv.numel() == self.world * send.numel()
+        self._check(self.library().ncclAllGather(send.data_ptr(), recv.data_ptr(), send.numel(), self.FLOAT64, self._comm,
+                                                 self._stream()), 'ncclAllGather')
+
+    def all_reduce_sum_(self, buf: Tensor) -> None:
+        assert buf.is_contiguous()
+        self._check(self.library().ncclAllReduce(buf.data_ptr(), buf.data_ptr(), buf.numel(), self.FLOAT64, self.SUM,
+                                                 self._comm, self._stream()), 'ncclAllReduce')
 
 
 def world_and_rank(group=None) -> Tuple[int, int]:
@@ -51,8 +136,9 @@ class EliteExchange:
     the status words.
     """
 
-    def __init__(self, iterations: int, episodes: int, k: int, row_len: int, group, device, dtype=torch.float64):
+    def __init__(self, iterations: int, episodes: int, k: int, row_len: int, group, device, dtype=torch.float64, comm=None):
         self.group = group
+        self.comm = comm     # an RcclComm: the collective goes straight onto the compute stream
         self.world, self.rank = world_and_rank(group)
         self.E, self.k, self.L = episodes, k, row_len
         self.gather = episodes == 1
@@ -91,11 +177,17 @@ class EliteExchange:
         if self.gather:
             if status is not None:
                 self.local[it, self.k, 2] = status[0]
-            dist.all_gather_into_tensor(self.buf[it].view(-1), self.local[it].view(-1), group=self.group)
+            if self.comm is not None:
+                self.comm.all_gather(self.local[it].view(-1), self.buf[it].view(-1))
+            else:
+                dist.all_gather_into_tensor(self.buf[it].view(-1), self.local[it].view(-1), group=self.group)
             words = self.buf[it, :, self.k, 2].to(torch.int32) if status is not None else None
             return self.buf[it].view(1, self.world * self.rows, 2 + self.L), words
         if status is not None:
             self.buf[it, self.n_slots + self.rank] = status[0]
-        dist.all_reduce(self.buf[it], op=dist.ReduceOp.SUM, group=self.group)
+        if self.comm is not None:
+            self.comm.all_reduce_sum_(self.buf[it])
+        else:
+            dist.all_reduce(self.buf[it], op=dist.ReduceOp.SUM, group=self.group)
         words = self.buf[it, self.n_slots:].to(torch.int32) if status is not None else None
         return self.slots(it).view(self.E, self.world * self.k, 2 + self.L), words

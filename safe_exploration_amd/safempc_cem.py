@@ -282,9 +282,10 @@ class CemSafeMPC(SafeMPC):
     def _solver(self):
         if self._injected_mpc:
             return self._mpc
-        if getattr(self._ssm, 'kernel_family', None) not in ('rbf', 'feature', 'mlp'):
+        if getattr(self._ssm, 'kernel_family', None) not in ('rbf', 'feature', 'mlp', 'stepwise'):
             raise NotImplementedError('the fused CEM solver needs a HIP-backed CemSSM (GpCemSSM, McDropoutSSM, '
-                                      'GalConcreteDropoutSSM); other CemSSMs are outside the accelerated path')
+                                      'GalConcreteDropoutSSM, or JunkDimensionsSSM over one of them); other CemSSMs are outside '
+                                      'the accelerated path')
         # the problem constants only change when the environment moves its objective (the pendulum's target angle,
         # environments.py:505-510): probe the hook at two fixed points and rebuild sx_env only when the answers change
         probe = self._env_objective_cost_func(self._objective_probe)

@@ -89,8 +89,16 @@ class JunkDimensionsSSM(CemSSM):
     Mirrors the reference exactly, including where the junk goes: states -> [states, junk], actions -> [actions, junk],
     raw inputs -> [z, all junk]; outputs are cut back to the leading real dimensions (the Jacobian to its leading
     n_s + n_u columns, as the reference does).  It works with any CemSSM at this surface -- the HIP-backed GpCemSSM as
-    long as the padded sizes stay within its limits (n_s <= 4, n_u <= 2); the fused CEM solver itself takes a GpCemSSM.
+    long as the padded sizes stay within its limits (n_s <= 4, n_u <= 2).
+
+    The CEM solver (CemSafeMPC / FusedCemMpc) takes the wrapper too, through its STEP-BY-STEP rollout (`kernel_family =
+    'stepwise'`: H x (predict through this wrapper + sx_onestep_reach) per CEM iteration, the way the reference's optimiser
+    drives its dynamics callback), not through the fused kernel: the wrapper's placement of the junk is not a GP over the
+    real dimensions -- training rows are [z, junk] but queries [states, junk, actions, junk], so with junk states the
+    action meets training columns that only ever held zeros, and the "action" columns of the returned Jacobian are
+    derivatives with respect to junk STATE inputs -- and the step-by-step path reproduces exactly that, whatever it means.
     """
+    kernel_family = 'stepwise'
 
     def __init__(self, constructor: Callable[..., CemSSM], state_dimen: int, action_dimen: int, junk_states: int,
                  junk_actions: int):

@@ -653,6 +653,60 @@ def test_junk_dimensions_wrapper_over_the_hip_gp():
     assert torch.equal(m2, mean) and tuple(v2.shape) == (11, 2)
 
 
+def test_get_action_through_junk_dimensions_matches_oracle():
+    """The reference's junk-dimension experiment configuration (utils_config.py:45-47: junk_state_dimen / junk_action_dimen,
+    ssm_cem.py:134-210; notebooks/results.ipynb cells 14-15 time the solver against it) through CemSafeMPC.get_action: the
+    solver rolls the wrapper out step by step (kernel_family 'stepwise'), and the selected actions equal the oracle's CEM
+    solve over a model that pads exactly as the reference does -- training rows [z, junk], queries [states, junk, actions,
+    junk], outputs and Jacobian cut back to their leading entries."""
+    import functools
+    from safe_exploration_amd import problems
+    from safe_exploration_amd.safempc_cem import CemSafeMPC, MpcResult, construct_constraints
+    from safe_exploration_amd.ssm_cem.gp_ssm_cem import GpCemSSM
+    from safe_exploration_amd.ssm_cem.ssm_cem import JunkDimensionsSSM
+    js, ja = 2, 1
+    spec = problems.pendulum(n_train=90, seed=5, obj_mode=0)
+    env = Env(spec, False)
+    ssm = JunkDimensionsSSM(functools.partial(GpCemSSM, Conf()), state_dimen=2, action_dimen=1, junk_states=js, junk_actions=ja)
+    rng = np.random.default_rng(8)
+    ls = np.concatenate((spec.lengthscale, rng.uniform(0.6, 1.2, size=(2, 3))), 1)      # [n_s x 6] for the two real outputs
+    ls = np.concatenate((ls, rng.uniform(0.6, 1.2, size=(js, 6))), 0)                   # ... and the junk outputs
+    s_out = np.concatenate((spec.outputscale, np.full(js, 0.01)))
+    nz = np.concatenate((spec.noise, np.full(js, 1e-5)))
+    ssm._ssm.set_hyperparameters(ls, s_out, nz)
+    solver = CemSafeMPC(ssm, construct_constraints(Conf(), env), env, Conf(), {'lin_model': (spec.a, spec.b)},
+                        wx_feedback_cost=np.diag([1.0, 2.0]), wu_feedback_cost=25.0 * np.eye(1), beta_safety=spec.beta,
+                        safe_policy=lambda x: spec.k_fb @ x)
+    y = spec.Y + spec.X[:, :2] @ spec.a.T + spec.X[:, 2:] @ spec.b.T
+    solver.update_model(spec.X, y, opt_hyp=False, replace_old=True)
+
+    class PaddedGP:
+        """the oracle's exact GP behind the reference's padding"""
+        def __init__(self):
+            n = spec.X.shape[0]
+            self.gp = ExactGP(np.concatenate((spec.X, np.zeros((n, js + ja))), 1),
+                              np.concatenate((ssm.y_train.cpu().numpy(), np.zeros((n, js))), 1), ls, s_out, nz)
+
+        def predict(self, z, jacobians=True):
+            zq = np.zeros((z.shape[0], 3 + js + ja))
+            zq[:, :2], zq[:, 2 + js:3 + js] = z[:, :2], z[:, 2:]
+            m, v, j = self.gp.predict(zq, jacobians)
+            return m[:, :2], v[:, :2], (j[:, :2, :3] if jacobians else None)
+
+    c = Conf
+    noise = rng.normal(size=(c.cem_num_iterations, c.cem_num_rollouts, c.mpc_time_horizon, 1))
+    x0 = np.array([0.01, -0.02])
+    mpc = solver._solver()
+    it = iter(noise)
+    mpc.sample_noise = lambda episodes=1: T(next(it)[None])
+    action, result = solver.get_action(x0)
+    ref_best, _ = ocem.cem_solve(problems.oracle_problem(spec, ocem), PaddedGP(), x0, noise, c.cem_num_elites,
+                                 init_std=np.full((c.mpc_time_horizon, 1), c.cem_init_std))
+    assert ref_best is not None and result == MpcResult.FOUND_SOLUTION
+    np.testing.assert_allclose(action, ref_best[0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(solver._last_mpc_actions, ref_best, rtol=0, atol=1e-9)
+
+
 def test_solve_fuzz_small():
     """A short run of tools/solve_fuzz.py: random small problems (training-set size, episodes, particles, horizon, elites,
     iterations, start spread), whole solves against the oracle's CEM loop with the same noise."""

@@ -17,7 +17,7 @@ from torch import Tensor
 
 
 class _NcclUniqueId(ctypes.Structure):
-    _fields_ = [('internal', ctypes.c_char * 128)]
+    _fields_ = [('internal', ctypes.c_byte * 128)]   # (c_byte: a c_char array reads back truncated at the first NUL)
 
 
 class RcclComm:
@@ -70,9 +70,10 @@ class RcclComm:
         uid = _NcclUniqueId()
         if self.rank == 0:
             self._check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
-        payload = [bytes(uid.internal)] if self.rank == 0 else [None]
+        payload = [ctypes.string_at(ctypes.byref(uid), 128)] if self.rank == 0 else [None]
         if self.world > 1:
             dist.broadcast_object_list(payload, src=dist.get_global_rank(group, 0), group=group)
+        assert len(payload[0]) == 128
         ctypes.memmove(ctypes.byref(uid), payload[0], 128)
         self._comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):

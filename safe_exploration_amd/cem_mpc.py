@@ -147,6 +147,8 @@ def cem_rollout_stepwise(ssm: GpCemSSM, env: _lib.SxEnv, x0: Tensor, actions: Te
             jac = None
         else:
             mean, var, jac = ssm.predict_with_jacobians(p, u)
+            jac = jac.contiguous()
+        mean, var = mean.contiguous(), var.contiguous()     # (a wrapping CemSSM may hand back slices: JunkDimensionsSSM)
         if group is not None:
             # the batch spans the ranks: if ANY rank holds an exact zero, every rank lifts its non-positive variances
             zero_any = (var == 0).any().to(torch.int32).reshape(1)

@@ -165,6 +165,8 @@ def objective_spec(env) -> Optional[Tuple[int, np.ndarray, np.ndarray, np.ndarra
             x = np.zeros((4, n_s))
             x[:, i] = [-2 * far, -far, far, 2 * far]
             c = hook(x)
+            if not np.all(np.isfinite(c)):
+                return None          # a hook that is not finite far out is not of this form: evaluate it as given
             s_lo, s_hi = (c[1] - c[0]) / far, (c[3] - c[2]) / far
             w_abs[i], w_lin[i] = 0.5 * (s_hi - s_lo), 0.5 * (s_hi + s_lo)
             if abs(w_abs[i]) <= 1e-12:
@@ -175,6 +177,18 @@ def objective_spec(env) -> Optional[Tuple[int, np.ndarray, np.ndarray, np.ndarra
             far = float(2.0 ** np.ceil(np.log2(2.0 * abs(target[i]) + 2.0)))
         if abs(w_lin[i]) < 1e-12 * max(1.0, abs(w_abs[i])):    # (rounding of the two slopes)
             w_lin[i] = 0.0
+        if w_abs[i] != 0.0:
+            # Third pass: the kink to the LAST BIT.  With a < t < b close to it, cost(b) - cost(a) = w (a + b - 2 t) + v (b - a)
+            # holds exactly in a, b (the doubles actually probed), so t follows with an error of a few ulp of w * delta --
+            # far below half an ulp of t: rounding the result gives the double the environment holds (the pendulum's
+            # target angle), where the crossing of two lines fitted at |x| ~ 2048 was only good to ~1e-15.
+            delta = 2.0 ** -8 * max(1.0, abs(target[i]))
+            a, b = float(target[i] - delta), float(target[i] + delta)
+            x = np.zeros((2, n_s))
+            x[:, i] = [a, b]
+            ca, cb = hook(x)
+            if np.isfinite(ca) and np.isfinite(cb):
+                target[i] = 0.5 * (a + b) - ((cb - ca) - w_lin[i] * (b - a)) / (2.0 * w_abs[i])
     test = np.random.default_rng(0).normal(size=(16, n_s))
     want = (np.abs(target[None] - test) * w_abs[None]).sum(1) + test @ w_lin
     if np.allclose(hook(test), want, rtol=1e-9, atol=1e-9):

@@ -14,6 +14,22 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """Tests marked `gpu` SKIP on a host without one (the driver runs `-m "not gpu"` here and `-m gpu` on the MI355X box; a
+    bare `pytest tests/` on a CPU host used to fail ten of them with 'No HIP GPUs are available': ADVICE r2)."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:   # noqa: BLE001
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason='needs an MI355X (no GPU on this host)')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

@@ -209,8 +209,17 @@ def test_objective_spec_mapping():
     mode, w_abs, tgt, w_lin = objective_spec(FakePendulum(False))
     assert mode == _lib.SX_OBJ_NEG_VARIANCE
     mode, w_abs, tgt, w_lin = objective_spec(FakePendulum(True))
-    # (identified by probing the public hook: the kink to rounding, not to the bit)
-    assert mode == _lib.SX_OBJ_AFFINE_ABS and w_abs.tolist() == [0, 1] and tgt[0] == 0 and abs(tgt[1] + 0.1) < 1e-14
+    # identified by probing the public hook alone -- and to the bit: the third pass recovers the double the environment holds
+    assert mode == _lib.SX_OBJ_AFFINE_ABS and w_abs.tolist() == [0, 1] and tgt[0] == 0 and tgt[1] == -0.1
+    for target in (0.3, -1e-3, 17.123456789, 0.0):        # other kinks, also exactly
+        env = FakePendulum(True)
+        env._current_objective = target
+        assert objective_spec(env)[2][1] == target
+
+    class Blows(FakePendulum):        # not finite far out: not of the separable form -> the hook path
+        def objective_cost_function(self, ps):
+            return torch.where(ps[:, 1].abs() > 100, torch.full_like(ps[:, 1], float('inf')), (ps[:, 1] + 0.1).abs())
+    assert objective_spec(Blows(True)) is None
     mode, w_abs, tgt, w_lin = objective_spec(FakeLander())
     assert mode == _lib.SX_OBJ_AFFINE_ABS and w_lin.tolist() == [0, 0, 0, 0, 0, -1] and not w_abs.any()
 

@@ -1,0 +1,23 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+from safe_exploration_amd import problems
+from safe_exploration_amd.cem_mpc import FusedCemMpc
+dev = torch.device('cuda:0')
+cands = {
+ 'a': (np.array([[0.7,0.9,0.6],[0.8,0.65,1.0]]), np.array([0.01,0.008]), np.array([1e-5,2e-5])),
+ 'b': (np.array([[0.75,0.9,0.65],[0.65,0.8,0.9]]), np.array([0.01,0.0125]), np.array([1e-5,2e-5])),
+ 'c': (np.array([[0.8,1.0,0.7],[0.7,0.85,1.1]]), np.array([0.009,0.012]), np.array([1e-5,1.5e-5])),
+ 'd': (np.array([[0.7,0.9,0.6],[0.55,0.8,1.1]]), np.array([0.01,0.01]), np.array([1e-5,2e-5])),
+}
+w = problems.baseline_workload(2)
+for name,(ls,os_,nz) in cands.items():
+    spec = w.spec
+    spec.lengthscale, spec.outputscale, spec.noise = ls, os_, nz
+    ssm, env = problems.build(spec, dev)
+    mpc = FusedCemMpc(ssm, env, w.horizon, w.particles, w.elites, w.iterations, device=dev, seed=1, init_std=w.init_std)
+    x0 = torch.tensor(w.x0[:1], dtype=torch.float64, device=dev)
+    oks=[]
+    for _ in range(6):
+        best, ok, _, status = mpc.solve(x0)
+        oks.append(int(ok[0].item()))
+    print(name, oks, int(status.item()))

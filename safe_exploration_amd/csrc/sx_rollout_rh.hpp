@@ -45,6 +45,9 @@
 #ifndef SX_RH_PRIO
 #define SX_RH_PRIO 0       // matrix phase: waves 0 .. 3 at raised priority (measured: 126.1 against 125.3 us without -- off)
 #endif
+#ifndef SX_RH_WFIRST
+#define SX_RH_WFIRST 0     // 1: request the resident W before anything else (the first version; A/B switch)
+#endif
 #ifndef SX_RH_SHARES
 #define SX_RH_SHARES 4, 4, 4, 1, 4, 4, 4   // Kstar phase: relative shares of waves 1 .. 7 (25 pairs of 8 rows at N = 200; wave 4 also runs finish_costs)
 #endif
@@ -375,17 +378,25 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
     // W overflow, [8 waves][LDSP][64 lanes] of 16 bytes (every piece before it is a multiple of 16 bytes long)
     v2d* const wlds = reinterpret_cast<v2d*>(kl.xbar + ((D + 1) & ~1));
 
-    // this wave's resident share of W (stream positions [0, REGP) to registers, [REGP, REGP + LDSP) to LDS): requested
-    // first, it travels while the rest is set up
+    // This wave's resident share of W (stream positions [0, REGP) to registers, [REGP, REGP + LDSP) to LDS) is requested
+    // BEHIND the first tile's prologue (below, `first_tile`): loads return in order, so with the 272 KB of W per workgroup
+    // requested first -- as the first version did -- everything the prologue loads (table, X rows, elite rows, noise) waited
+    // behind it, ~2.7 us of a launch's ~10 us of fixed cost (tools/horizon_sweep.sh).  Requested last, W travels under the
+    // first Kstar phase; the LDS part goes by DMA (buffer_load ... lds: no staging registers), awaited before the first
+    // matrix phase's barrier.
     static constexpr RhStream<NS, NRB, MAXP> stream{};
-    const v2d* __restrict__ const ap = reinterpret_cast<const v2d*>(gc.a_pack) + lane;
     v2d wreg[REGP];
+#if SX_RH_WFIRST   // (A/B switch: the first version's order)
+    {
+        const v2d* __restrict__ const ap0 = reinterpret_cast<const v2d*>(gc.a_pack) + lane;
 #pragma unroll
-    for (int i = 0; i < REGP; ++i) wreg[i] = ap[(size_t)stream.pair[wave][i] * 64];
-    if constexpr (LDSP > 0) {
+        for (int i = 0; i < REGP; ++i) wreg[i] = ap0[(size_t)stream.pair[wave][i] * 64];
+        if constexpr (LDSP > 0) {
 #pragma unroll
-        for (int i = 0; i < LDSP; ++i) wlds[(wave * LDSP + i) * 64 + lane] = ap[(size_t)stream.pair[wave][REGP + i] * 64];
+            for (int i = 0; i < LDSP; ++i) wlds[(wave * LDSP + i) * 64 + lane] = ap0[(size_t)stream.pair[wave][REGP + i] * 64];
+        }
     }
+#endif
     {
         static_assert(sizeof(RwConst<NS, NU>) % 8 == 0 && sizeof(ReachConst<NS, NU>) % 8 == 0 &&
                       sizeof(CostConst<SX_MAX_M, NS, NU>) % 8 == 0, "copied in 8-byte words");
@@ -505,6 +516,22 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
         }
         __syncthreads();
 
+        if (!SX_RH_WFIRST && tile == (int)blockIdx.x) {     // the first tile of this workgroup: now request the resident W
+            const v2d* __restrict__ const ap = reinterpret_cast<const v2d*>(gc.a_pack) + lane;
+            if constexpr (LDSP > 0) {
+                const __amdgpu_buffer_rsrc_t arsrc =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(gc.a_pack), 0, (int)0xffffffffu, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < LDSP; ++i) {
+                    const int pair = __builtin_amdgcn_readfirstlane(stream.pair[wave][REGP + i]);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        arsrc, (__attribute__((address_space(3))) void*)(wlds + (wave * LDSP + i) * 64), 16, lane * 16, pair << 10, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < REGP; ++i) wreg[i] = ap[(size_t)stream.pair[wave][i] * 64];
+        }
+
         // centre of particle c at step t >= 1 from z_{t-1} and the means of step t - 1 (cem_rollout_kernel's chain, bit for bit)
         auto next_centre = [&](const ReachConst<NS, NU>& R, int c, const double* z_prev, double (&out)[NS]) {
 #pragma unroll
@@ -620,28 +647,50 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
         auto finish_costs = [&](int t) {
             const int c = lane & 15;
             const double* o = st_row((t + 1) & 1, c);
-            double pp[NS], QQ[NS][NS];
+            // (all LDS operands requested in one batch, as in finish_state: the state row, this lane's first polytope row,
+            // the action, the cost sums and the objective's constants)
+            double pp[NS], QQ[NS][NS], var[NS], hrow[NS], hv, uu[NU], umin[NU], umax[NU], wab[NS], tgt[NS], wli[NS];
+            const int m = fcc.m, obj_mode = fcc.obj_mode, con_mode = fcc.con_mode;
+            const int r0 = lane >> 4;
+            const int r0c = r0 < m ? r0 : 0;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 pp[i] = o[i];
 #pragma unroll
                 for (int j = 0; j < NS; ++j) QQ[i][j] = o[NS + i * NS + j];
+                var[i] = o[S + i];
+                hrow[i] = fcc.h_mat[r0c * NS + i];
+                wab[i] = fcc.w_abs[i];
+                tgt[i] = fcc.target[i];
+                wli[i] = fcc.w_lin[i];
             }
+            hv = fcc.h_vec[r0c];
+#pragma unroll
+            for (int cidx = 0; cidx < NU; ++cidx) {
+                uu[cidx] = acts[(c * H + t) * NU + cidx];
+                umin[cidx] = fcc.u_min[cidx];
+                umax[cidx] = fcc.u_max[cidx];
+            }
+            double obj = ac_row[0], con = ac_row[1];
+            SX_PIN();
             bool viol = false;
-            if (fcc.con_mode == SX_CON_ALL_STATES || t == H - 1) {
-                const int m = fcc.m;
-                for (int r = lane >> 4; r < m; r += 4) {
+            if (con_mode == SX_CON_ALL_STATES || t == H - 1) {
+                for (int r = r0; r < m; r += 4) {
+                    if (r != r0) {     // (polytopes of more than 4 rows: the further rows of this lane)
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) hrow[i] = fcc.h_mat[r * NS + i];
+                        hv = fcc.h_vec[r];
+                    }
                     double hc = 0.0, hq = 0.0;
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
-                        const double hi = fcc.h_mat[r * NS + i];
-                        hc += hi * pp[i];
+                        hc += hrow[i] * pp[i];
                         double sacc = 0.0;
 #pragma unroll
-                        for (int j = 0; j < NS; ++j) sacc += QQ[i][j] * fcc.h_mat[r * NS + j];
-                        hq += hi * sacc;
+                        for (int j = 0; j < NS; ++j) sacc += QQ[i][j] * hrow[j];
+                        hq += hrow[i] * sacc;
                     }
-                    const double dist = hc + sqrt(hq) - fcc.h_vec[r];
+                    const double dist = hc + sqrt(hq) - hv;
                     viol = viol || (dist >= 0.0);
                 }
             }
@@ -649,20 +698,24 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
             bits |= bits >> 32;
             bits |= bits >> 16;
             if (lane_owner) {
-                double var[NS];
-#pragma unroll
-                for (int i = 0; i < NS; ++i) var[i] = o[S + i];
-                double con = ac_row[1];
                 if ((bits >> lane) & 1ull) con += SX_STATE_VIOLATION_COST;
                 bool uviol = false;
 #pragma unroll
-                for (int cidx = 0; cidx < NU; ++cidx) {
-                    const double uu = acts[(lane * H + t) * NU + cidx];
-                    uviol = uviol || (uu < fcc.u_min[cidx]) || (uu > fcc.u_max[cidx]);
-                }
+                for (int cidx = 0; cidx < NU; ++cidx) uviol = uviol || (uu[cidx] < umin[cidx]) || (uu[cidx] > umax[cidx]);
                 if (uviol) con += SX_ACTION_VIOLATION_COST;
+                // objective (safempc_cem.py:304-312): -sum of the predicted variances, or the affine-abs form of the hook
+                // (objective_cost's operation order: the step's cost is summed from 0, then added)
+                double oadd = 0.0;
+                if (obj_mode == SX_OBJ_NEG_VARIANCE) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) oadd -= var[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) oadd += wab[i] * fabs(tgt[i] - pp[i]) + wli[i] * pp[i];
+                }
+                obj += oadd;
+                ac_row[0] = obj;
                 ac_row[1] = con;
-                ac_row[0] += objective_cost<SX_MAX_M, NS, NU>(fcc, pp, var);
                 const int64_t g = (int64_t)e * rp.P + c0 + lane;
                 if (lane_valid && rp.traj) {
                     double* tr = rp.traj + (g * H + t) * S;
@@ -700,6 +753,8 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
                     for (int j = 0; j < D; ++j) zq[j] = zs_base[c * D + j];
                     rw_kstar_phase(gc, kl, lds.kfrag, q0_begin, q0_end, zq);
                 } else {
+                    // (requesting the first trip's rows here, ahead of next_centre's round trip -- rw_kstar_prefetch -- costs
+                    // 20 more live registers than this kernel has: 39 spilled dwords; not done)
                     double pc[NS];
                     next_centre(rc, c, zs_base + ((t - 1) & 1) * 16 * D + c * D, pc);
 #pragma unroll
@@ -714,6 +769,7 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
 #ifdef SX_STAMPS
             const unsigned long long t1 = stamp();
 #endif
+            if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the W pairs on their way to LDS by DMA)
             __syncthreads();
 #ifdef SX_STAMPS
             const unsigned long long t2 = stamp();

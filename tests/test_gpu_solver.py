@@ -707,6 +707,26 @@ def test_get_action_through_junk_dimensions_matches_oracle():
     np.testing.assert_allclose(solver._last_mpc_actions, ref_best, rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize('form', ['rh', 'rw', 'stream'])
+def test_every_form_of_the_fused_rollout_vs_oracle(form):
+    """The three forms of the fused rollout kernel (8 waves with W partly resident -- the default where it is
+    instantiated --, 4 waves with W in the register file, W streamed from L2), each forced through SX_ROLLOUT in a process of
+    its own (the library reads the switch once) and checked against the oracle on every (n_s, n_u) it is built for and on
+    training-set sizes on and off the 16-row grid (tools/rw_repro.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = {'rh': ['2,1,77', '1,1,77', '2,2,77', '2,1,200', '2,1,197', '1,1,9'],
+              'rw': ['2,1,77', '1,1,77', '3,1,77', '4,1,50', '4,2,40', '2,2,120', '2,1,200'],
+              'stream': ['2,1,77', '4,2,60', '3,1,77', '2,1,260']}[form]
+    env = dict(os.environ, SX_ROLLOUT=form, SX_ROLLOUT_STRICT='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rw_repro.py')] + shapes, capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0 and 'Memory access fault' not in r.stdout + r.stderr, r.stdout[-3000:] + r.stderr[-2000:]
+    want = {'rh': 'form 2', 'rw': 'form 1', 'stream': 'form 0'}[form]
+    assert r.stdout.count('matches the oracle; ' + want) == len(shapes), r.stdout[-3000:]
+
+
 def test_solve_fuzz_small():
     """A short run of tools/solve_fuzz.py: random small problems (training-set size, episodes, particles, horizon, elites,
     iterations, start spread), whole solves against the oracle's CEM loop with the same noise."""

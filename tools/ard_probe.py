@@ -4,10 +4,11 @@ from safe_exploration_amd import problems
 from safe_exploration_amd.cem_mpc import FusedCemMpc
 dev = torch.device('cuda:0')
 cands = {
- 'a': (np.array([[0.7,0.9,0.6],[0.8,0.65,1.0]]), np.array([0.01,0.008]), np.array([1e-5,2e-5])),
- 'b': (np.array([[0.75,0.9,0.65],[0.65,0.8,0.9]]), np.array([0.01,0.0125]), np.array([1e-5,2e-5])),
- 'c': (np.array([[0.8,1.0,0.7],[0.7,0.85,1.1]]), np.array([0.009,0.012]), np.array([1e-5,1.5e-5])),
- 'd': (np.array([[0.7,0.9,0.6],[0.55,0.8,1.1]]), np.array([0.01,0.01]), np.array([1e-5,2e-5])),
+ 'e': (np.array([[0.8,1.0,0.7],[0.9,0.75,1.2]]), np.array([0.006,0.004]), np.array([1e-5,2e-5])),
+ 'f': (np.array([[0.9,1.1,0.8],[1.0,0.85,1.3]]), np.array([0.008,0.005]), np.array([1e-5,1.5e-5])),
+ 'g': (np.array([[0.75,0.7,0.7],[0.7,0.72,0.75]]), np.array([0.009,0.0085]), np.array([1e-5,1.1e-5])),
+ 'h': (np.array([[0.7,0.7,0.7],[0.7,0.7,0.7]]), np.array([0.01,0.01]), np.array([1e-5,1e-5])),
+ 'i': (np.array([[1.0,1.2,0.9],[1.1,0.95,1.4]]), np.array([0.005,0.003]), np.array([1e-5,2e-5])),
 }
 w = problems.baseline_workload(2)
 for name,(ls,os_,nz) in cands.items():

@@ -99,8 +99,14 @@ def mlp_flops_per_particle_step(widths, d_in, n_s, n_out, members):
     return 2 * members * (fwd + n_s * bwd)
 
 
+# the kernel classes the roofline object can be about (the fused rollout of the GP / degenerate-kernel / MC-dropout models)
+# (SX_PROF_ROLLOUT_FUSED, SX_PROF_ROLLOUT_FEAT, SX_PROF_ROLLOUT_MLP of include/sx_amd.h)
+DOMINANT_KINDS = (0, 5, 6)
+DOMINANT_KERNELS = ('cem_rollout_kernel', 'cem_rollout_feat_kernel', 'cem_rollout_mlp_kernel')
+
+
 def PROFILE_STRIDE(cfg, launches=None):
-    """Every n-th launch of a kernel class is bracketed by HIP events: 16 costs < 1 % (every launch 7 %), but at least ~50
+    """Every n-th launch of a kernel class carries HIP events: 16 costs < 1 % (every launch 7 %), but at least ~50
     launches must be timed -- the driver's `--steps 20` is 160 rollout launches."""
     if cfg == 4:
         return 1
@@ -133,8 +139,10 @@ def total_mfmas(form, n_s):
     return waves if waves % n_s == 0 else waves * n_s     # (upper bound for the ungrouped plans: n_s = 3)
 
 
-# what a pair of HIP events adds to the launch it brackets (the 7.8 us ranking kernel reads 10.6 us through events)
-EVENT_OVERHEAD_US = 2.8
+# The card needs ~50 ms of work to reach its steady clock after the set-up's idle stretches (tools/timer_sweep.sh,
+# profiles/r03_timer_sweep.txt: the same 20 timed solves read 2.5-4 % slower behind 5 warm-up solves than behind 50).  Before
+# the W warm-up steps bench.py therefore runs untimed solves for this long; the JSON line says how many (`prewarm_solves`).
+PREWARM_S = 0.10
 
 
 def cpu_baseline(w, budget_s=12.0):
@@ -287,6 +295,8 @@ def main():
     ap.add_argument('--no-exchange-timer', action='store_true', help='no events around the multi-GPU exchange (exchange_us null)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true', help='leave the per-launch HIP events off (no roofline object)')
+    ap.add_argument('--profile-stride', type=int, default=0,
+                    help='bracket every n-th launch of a kernel with HIP events (0 = PROFILE_STRIDE: 16, less in short runs)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -379,12 +389,25 @@ def main():
             dist.barrier(group)
         torch.cuda.synchronize(dev)
 
+    def prewarm(one_step):
+        # untimed: the card to its steady clock (PREWARM_S above) before the W warm-up steps
+        n, t_end = 0, time.perf_counter() + PREWARM_S
+        while time.perf_counter() < t_end:
+            one_step()
+            torch.cuda.synchronize(dev)
+            n += 1
+        return n
+
     def start_timer():
         if not args.no_kernel_timer:
             # HIP events on every 16th launch of each kernel (every launch of the large-N path, whose kernels run for
-            # milliseconds): timing every 130 us launch costs the solve ~7 % (measured), every 4th 2.6 % (1.121 against
-            # 1.092 ms with the timer off), every 16th < 1 % -- 50 timed launches per kernel in the default run
-            _lib.check(lib.sx_profile_stride(PROFILE_STRIDE(w.cfg, steps * iters)), 'sx_profile_stride')
+            # milliseconds): timing every 130 us launch costs the solve ~7 % (measured), every 3rd 2.4 %, every 16th < 1 %
+            # (profiles/r03_timer_sweep.txt).  The dominant kernel: at least ~50 timed launches however short the run; the
+            # others every 16th at most
+            dominant = args.profile_stride or PROFILE_STRIDE(w.cfg, steps * iters)
+            _lib.check(lib.sx_profile_stride(max(dominant, 1 if w.cfg == 4 else 16)), 'sx_profile_stride')
+            for kind in DOMINANT_KINDS:
+                _lib.check(lib.sx_profile_stride_kind(kind, dominant), 'sx_profile_stride_kind')
             _lib.check(lib.sx_profile_enable(max(4096, steps * iters * (3 * H + 4))), 'sx_profile_enable')
 
     if w.cfg == 5:
@@ -402,6 +425,7 @@ def main():
         envs = [problems.StubEnv(spec, x, never_done=True) for x in x0.cpu().numpy()]
         solver, _ = problems.make_solver(spec, Conf(), envs[0], dev)
         mpc = solver._solver()
+        prewarm_solves = prewarm(lambda: do_rollout_batch(envs, 1, solver))
         do_rollout_batch(envs, warmup, solver)
         start_timer()
         barrier()
@@ -417,6 +441,7 @@ def main():
         mpc = FusedCemMpc(ssm, env, H, total_particles, elites, iters, device=dev, seed=1, init_std=init_std,
                           warm_start='safe_policy' if w.warm_start != 'zero' else 'zero', process_group=solver_group,
                           force_exchange=force_exchange)
+        prewarm_solves = prewarm(lambda: mpc.solve(x0))
         for _ in range(warmup):
             mpc.solve(x0)
         start_timer()
@@ -486,16 +511,18 @@ def main():
             particle_steps = (P * world if w.sharded else P * episodes_total) * H * iters * steps
             flops_unit = algorithmic_flops_per_particle_step(spec.n_s, n_train, d_in) if mlp is None else \
                 mlp_flops_per_particle_step(mlp['hidden'], d_in, spec.n_s, spec.n_s, mlp['members'])
-            stride = PROFILE_STRIDE(w.cfg, steps * iters)   # every stride-th launch of a kernel is timed (start_timer)
+            # every stride-th launch of a kernel class is timed (start_timer)
+            dominant = args.profile_stride or PROFILE_STRIDE(w.cfg, steps * iters)
+            stride_of = lambda k: dominant if k in DOMINANT_KERNELS else max(dominant, 1 if w.cfg == 4 else 16)
             form = int(lib.sx_cem_rollout_form(ctypes.byref(ssm.device_model), H)) if mlp is None else 0
-            # shares of the step NET of what the event pair adds to a launch it brackets (raw, the 8 us ranking kernel alone
-            # reads 35 % high and the shares summed to 1.017 in round 2); the sum is capped at 1
+            # the events are attached to the launch (sx_launch.hpp) and read the dispatch's own begin -> end, so the shares
+            # need no correction for marker packets (round 2's hipEventRecord pairs read 2.8 us high and summed to 1.017);
+            # the sum is still capped at 1
             per_kernel = {}
             for k, (ms, n) in kernels.items():
-                net_us = max(ms / n * 1e3 - EVENT_OVERHEAD_US, 0.0)
                 per_kernel[FORM_KERNEL.get(form, k) if k == 'cem_rollout_kernel' else k] = {
-                    'avg_launch_us': ms / n * 1e3, 'launches_timed': n, 'net_of_event_pair_us': net_us,
-                    'share_of_step': net_us * 1e-3 * n * stride / (elapsed * 1e3)}
+                    'avg_launch_us': ms / n * 1e3, 'launches_timed': n, 'every_nth_launch': stride_of(k),
+                    'share_of_step': ms * stride_of(k) / (elapsed * 1e3)}
             total_share = sum(v['share_of_step'] for v in per_kernel.values())
             if total_share > 1.0:
                 for v in per_kernel.values():
@@ -505,7 +532,8 @@ def main():
                 roofline = roofline_of(kernels, spec, n_train, d_in, E, P, H, flops_unit, w.cfg, mlp, form)
             out = {
                 'metric': 'cem_particle_step_evals_per_s', 'value': particle_steps / elapsed, 'unit': 'particle-steps/s',
-                'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
+                'n_gpus': world, 'steps': steps, 'warmup': warmup, 'prewarm_solves': prewarm_solves,
+                'ms_per_step': elapsed / steps * 1e3,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                 'config': {'workload': f'{w.name}: n_s={spec.n_s} n_u={spec.n_u}, '
                                        + (f'exact GP N_train={n_train}' if mlp is None else

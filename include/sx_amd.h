@@ -153,9 +153,12 @@ int sx_cem_rollout_mlp(const sx_mlp_model* model, const sx_env* env, int E, int 
                        double* sigma, double* obj_cost, double* con_cost, int32_t* status, void* stream);
 
 /* Optional kernel timer -- measurement support, not part of the reference's surface (it has no profiler: SURVEY.md 5).
- * While enabled, the launches of the path's kernels (every `sx_profile_stride`-th of each kind) are bracketed by a pair of
- * hipEventRecord on the stream the kernel is launched on (at most `max_launches` launches are recorded); sx_profile_collect synchronises those events and returns
- * the summed elapsed time and the launch count of one kernel class.  bench.py's `roofline.avg_launch_us` comes from here. */
+ * While enabled, the launches of the path's kernels (every `sx_profile_stride`-th of each kind) carry a start and a stop HIP
+ * event on the stream the kernel is launched on (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, the
+ * interval rocprofv3's kernel trace reports; SX_PROF_RECORD=1 in the environment: two hipEventRecord around the launch, as
+ * in rounds 1-2, which read ~2.8 us more).  At most `max_launches` launches are recorded; sx_profile_collect synchronises
+ * those events and returns the summed elapsed time and the launch count of one kernel class.  bench.py's
+ * `roofline.avg_launch_us` comes from here. */
 #define SX_PROF_ROLLOUT_FUSED 0  /* cem_rollout_kernel            */
 #define SX_PROF_RANK 1           /* cem_rank_kernel               */
 #define SX_PROF_KSTAR_BIG 2      /* kstar_big_kernel   (large-N path) */
@@ -165,8 +168,9 @@ int sx_cem_rollout_mlp(const sx_mlp_model* model, const sx_env* env, int E, int 
 #define SX_PROF_ROLLOUT_MLP 6    /* cem_rollout_mlp_mfma_kernel / cem_rollout_mlp_kernel (MC-dropout ensembles) */
 #define SX_PROF_KINDS 7
 int sx_profile_enable(int max_launches);
-int sx_profile_stride(int every);   /* time every n-th launch of a kernel class only (default 1): an event pair costs the
+int sx_profile_stride(int every);   /* time every n-th launch of a kernel class only (default 1): a timed launch costs the
                                        launch path a few microseconds, which a 130 us kernel notices */
+int sx_profile_stride_kind(int kind, int every);   /* the same for one kernel class */
 int sx_profile_collect(int kind, double* total_ms, int64_t* launches);
 int sx_profile_disable(void);
 

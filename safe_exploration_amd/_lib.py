@@ -90,6 +90,7 @@ SIGNATURES = {
     'sx_cem_rollout_workspace_bytes': (c_int64, [POINTER(SxGpModel), c_int, c_int, c_int]),
     'sx_profile_enable': (c_int, [c_int]),
     'sx_profile_stride': (c_int, [c_int]),
+    'sx_profile_stride_kind': (c_int, [c_int, c_int]),
     'sx_profile_collect': (c_int, [c_int, POINTER(c_double), POINTER(c_int64)]),
     'sx_profile_disable': (c_int, []),
     'sx_cem_rank_counts': (c_int, [c_int, c_int]),

@@ -283,8 +283,9 @@ static void make_cost_const(const sx_env* env, CostConst<SX_MAX_M, NS, NU>& cc) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Optional kernel timer (sx_profile_*): while enabled, every launch of the path's kernels is bracketed by a pair of
-// HIP events on the stream the kernel is launched on; sx_profile_collect adds the elapsed times up per kernel class.
+// Optional kernel timer (sx_profile_*): while enabled, every n-th launch of each of the path's kernel classes carries a
+// pair of HIP events on the stream the kernel is launched on (sx_launch.hpp); sx_profile_collect adds the elapsed times up
+// per kernel class.
 // This is how bench.py measures `roofline.avg_launch_us` live, inside its timed region.
 // ---------------------------------------------------------------------------------------------------------------
 struct ProfEntry {
@@ -294,7 +295,7 @@ struct ProfEntry {
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static size_t g_prof_cap = 0;
-static int g_prof_stride = 1;               // every n-th launch of a kernel class is timed
+static int g_prof_stride[SX_PROF_KINDS] = {1, 1, 1, 1, 1, 1, 1};   // every n-th launch of a kernel class is timed
 static long g_prof_seen[SX_PROF_KINDS] = {0};
 static std::vector<ProfEntry> g_prof_entries;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -304,7 +305,7 @@ bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop) {
     if (!g_prof_on) return false;   // (read without the lock: enabling mid-launch only loses that launch)
     std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof_on || g_prof_entries.size() >= g_prof_cap) return false;
-    if ((g_prof_seen[kind]++ % g_prof_stride) != 0) return false;
+    if ((g_prof_seen[kind]++ % g_prof_stride[kind]) != 0) return false;
     auto take = [&]() {
         hipEvent_t e = nullptr;
         if (!g_prof_pool.empty()) {
@@ -790,7 +791,14 @@ int sx_profile_enable(int max_launches) {
 int sx_profile_stride(int every) {
     if (every <= 0) return SX_ERR_ARG;
     std::lock_guard<std::mutex> lock(sx::g_prof_mu);
-    sx::g_prof_stride = every;
+    for (int& v : sx::g_prof_stride) v = every;
+    return SX_OK;
+}
+
+int sx_profile_stride_kind(int kind, int every) {
+    if (every <= 0 || kind < 0 || kind >= SX_PROF_KINDS) return SX_ERR_ARG;
+    std::lock_guard<std::mutex> lock(sx::g_prof_mu);
+    sx::g_prof_stride[kind] = every;
     return SX_OK;
 }
 

@@ -390,13 +390,23 @@ def main():
         torch.cuda.synchronize(dev)
 
     def prewarm(one_step):
-        # untimed: the card to its steady clock (PREWARM_S above) before the W warm-up steps
-        n, t_end = 0, time.perf_counter() + PREWARM_S
-        while time.perf_counter() < t_end:
+        # untimed: the card to its steady clock (PREWARM_S above) before the W warm-up steps.  The SAME number of steps on
+        # every rank (a sharded step holds a collective): the second step is timed, the slowest rank's time decides
+        one_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        one_step()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            dt = float(t.item())
+        n = max(1, min(int(PREWARM_S / max(dt, 1e-6)), 2000))
+        for _ in range(n):
             one_step()
-            torch.cuda.synchronize(dev)
-            n += 1
-        return n
+        torch.cuda.synchronize(dev)
+        return n + 2
 
     def start_timer():
         if not args.no_kernel_timer:

@@ -30,6 +30,12 @@
 #ifndef SX_RH_REGP
 #define SX_RH_REGP 26      // W fragment pairs per wave kept in registers (104 of the wave's 256)
 #endif
+#ifndef SX_RH_LEAD
+// Where the L2-streamed part of a wave's stream sits in its program: behind this many register-resident pairs, and BEFORE the
+// LDS and the other register pairs -- so the phase's tail, which one wave of a SIMD runs alone, needs no loads at all
+// (-1: at the end of the program, as first built).
+#define SX_RH_LEAD -1
+#endif
 #ifndef SX_RH_LDSP
 #define SX_RH_LDSP 8       // W fragment pairs per wave kept in LDS (8 waves x 8 KB)
 #endif
@@ -135,16 +141,39 @@ struct RhElements {
     }
 };
 
-// the same as pair offsets into a_pack; entries past the share repeat pair 0 (a valid address, never used)
-template <int NS, int NRB, int MAXP>
+// Where the A operand of a wave's e-th MFMA pair (consumption order) is kept.  STORAGE index s: s < REGP a register pair,
+// REGP <= s < REGP + LDSP a pair in the wave's LDS block, above that a pair streamed from L2 every step.  With `total`
+// pairs in the wave's stream: registers take min(REGP, total), LDS the next min(LDSP, rest), L2 what is left; consumption
+// order is [lead register pairs][L2][LDS][the other register pairs] (SX_RH_LEAD), or [registers][LDS][L2] (lead < 0).
+struct RhLayout {
+    int nr, nl, ng, lead;
+    constexpr RhLayout(int total, int regp, int ldsp)
+        : nr(total < regp ? total : regp), nl(0), ng(0), lead(0) {
+        nl = total - nr < ldsp ? total - nr : ldsp;
+        ng = total - nr - nl;
+        lead = SX_RH_LEAD < 0 || ng == 0 ? nr : (SX_RH_LEAD < nr ? SX_RH_LEAD : nr);
+    }
+    constexpr int storage(int e, int regp, int ldsp) const {
+        if (SX_RH_LEAD < 0 || ng == 0) return e;                              // [registers][LDS][L2]: storage order
+        if (e < lead) return e;
+        if (e < lead + ng) return regp + ldsp + (e - lead);
+        if (e < lead + ng + nl) return regp + (e - lead - ng);
+        return lead + (e - lead - ng - nl);
+    }
+};
+
+// pair offsets into a_pack by STORAGE index; entries past the share repeat pair 0 (a valid address, never used)
+template <int NS, int NRB, int MAXP, int REGP, int LDSP>
 struct RhStream {
     int pair[kRhWaves][MAXP];
     constexpr RhStream() : pair{} {
         const RhElements<NS, NRB> el{};
         constexpr int wpo = NRB * (NRB + 1);
         for (int w = 0; w < kRhWaves; ++w) {
-            for (int i = 0; i < MAXP; ++i)
-                pair[w][i] = i < el.n[w] ? el.d[w][i] * wpo + el.rb[w][i] * (el.rb[w][i] + 1) + el.q[w][i] : 0;
+            const RhLayout lay(el.n[w], REGP, LDSP);
+            for (int i = 0; i < MAXP; ++i) pair[w][i] = 0;
+            for (int e = 0; e < el.n[w]; ++e)
+                pair[w][lay.storage(e, REGP, LDSP)] = el.d[w][e] * wpo + el.rb[w][e] * (el.rb[w][e] + 1) + el.q[w][e];
         }
     }
 };
@@ -153,11 +182,12 @@ struct RhStream {
 enum RhOpKind { kRhLoadB = 0, kRhLoadWL = 1, kRhLoadWG = 2, kRhMfma = 3, kRhRowEpi = 4, kRhFinalEpi = 5 };
 struct RhOp {
     int kind;
-    int i;      // stream index (W loads, MFMA)
+    int i;      // storage index of the W pair (W loads, MFMA)
     int rb;     // row-block (MFMA, row epilogue)
     int q;      // Kstar pair (Kstar load, MFMA)
     int d;      // output
     int slot;   // Kstar register slot (Kstar load, MFMA)
+    int e;      // position in the wave's consumption order (MFMA)
 };
 template <int NS, int NRB, int WAVE, int REGP, int LDSP, int PF, int PFL, int PFG>
 struct RhProgram {
@@ -168,8 +198,11 @@ struct RhProgram {
     constexpr RhProgram() : ops{}, n(0), total(0) {
         const RhElements<NS, NRB> el{};
         total = el.n[WAVE];
-        int next_l = REGP;               // next LDS-resident pair to request
-        int next_g = REGP + LDSP;        // next streamed pair to request
+        const RhLayout lay(total, REGP, LDSP);
+        int next_l = 0;                  // next LDS-resident pair to request (count within the LDS part)
+        int next_g = 0;                  // next streamed pair to request (count within the L2 part)
+        const int e_g0 = (SX_RH_LEAD < 0 || lay.ng == 0) ? lay.nr + lay.nl : lay.lead;             // element of the first L2 pair
+        const int e_l0 = (SX_RH_LEAD < 0 || lay.ng == 0) ? lay.nr : lay.lead + lay.ng;             // ... first LDS pair
         // Kstar loads: one per MFMA pair (row-block-major) or one per (d, q) group (pair-major); `bl` = loads issued so far
         // in element order, each element knows the slot its Kstar pair sits in
         int bslot[RhElements<NS, NRB>::kMax] = {};
@@ -201,9 +234,9 @@ struct RhProgram {
         for (int e = 0; e < total; ++e) {
             if (bfirst[e]) ++loads_seen;
             issue_b_upto(loads_seen + PF);
-            while (next_l < total && next_l < REGP + LDSP && next_l <= e + PFL) ops[n++] = RhOp{kRhLoadWL, next_l++, 0, 0, 0, 0};
-            while (next_g < total && next_g <= e + PFG) ops[n++] = RhOp{kRhLoadWG, next_g++, 0, 0, 0, 0};
-            ops[n++] = RhOp{kRhMfma, e, el.rb[WAVE][e], el.q[WAVE][e], el.d[WAVE][e], bslot[e]};
+            while (next_l < lay.nl && e_l0 + next_l <= e + PFL) ops[n++] = RhOp{kRhLoadWL, REGP + next_l++, 0, 0, 0, 0};
+            while (next_g < lay.ng && e_g0 + next_g <= e + PFG) ops[n++] = RhOp{kRhLoadWG, REGP + LDSP + next_g++, 0, 0, 0, 0};
+            ops[n++] = RhOp{kRhMfma, lay.storage(e, REGP, LDSP), el.rb[WAVE][e], el.q[WAVE][e], el.d[WAVE][e], bslot[e], e};
             const bool last_of_rb = el.q[WAVE][e] == 2 * (el.rb[WAVE][e] + 1) - 1;
             if (last_of_rb) {
                 pend_rb[npend] = el.rb[WAVE][e];
@@ -232,7 +265,7 @@ __device__ __forceinline__ void rh_mfma_phase(const GpConst<NS, D>& gc, GpTileLd
     constexpr int PF = SX_RW_PF, PFL = SX_RH_PFL, PFG = SX_RH_PFG;
     constexpr int MAXP = RhPlan<NS, NRB>{}.max_pairs();
     static constexpr RhProgram<NS, NRB, WAVE, REGP, LDSP, PF, PFL, PFG> prog{};
-    static constexpr RhStream<NS, NRB, MAXP> stream{};
+    static constexpr RhStream<NS, NRB, MAXP, REGP, LDSP> stream{};
     const v2d* kbase = reinterpret_cast<const v2d*>(lds.kfrag) + lane;
     // (the streamed pairs are the same every step: hidden behind an opaque copy of the pointer, or the compiler hoists
     // their loads out of the step loop and spills what it hoisted)
@@ -260,6 +293,11 @@ __device__ __forceinline__ void rh_mfma_phase(const GpConst<NS, D>& gc, GpTileLd
         } else if constexpr (op.kind == kRhLoadWG) {
             wg[op.i % (PFG + 1)] = ap[(size_t)stream.pair[WAVE][op.i] * 64];
         } else if constexpr (op.kind == kRhMfma) {
+#if SX_RH_PRIO == 2
+            // progress-based priority: a wave that is behind its SIMD partner (in quarters of its own program) wins the pipe
+            if constexpr ((4 * op.e) / prog.total != (4 * (op.e - 1)) / prog.total || op.e == 0)
+                __builtin_amdgcn_s_setprio(3 - (4 * op.e) / prog.total);
+#endif
             SX_PIN();
             const v2d bq = b[op.slot];
             v2d a;
@@ -384,7 +422,7 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
     // behind it, ~2.7 us of a launch's ~10 us of fixed cost (tools/horizon_sweep.sh).  Requested last, W travels under the
     // first Kstar phase; the LDS part goes by DMA (buffer_load ... lds: no staging registers), awaited before the first
     // matrix phase's barrier.
-    static constexpr RhStream<NS, NRB, MAXP> stream{};
+    static constexpr RhStream<NS, NRB, MAXP, REGP, LDSP> stream{};
     v2d wreg[REGP];
 #if SX_RH_WFIRST   // (A/B switch: the first version's order)
     {
@@ -439,6 +477,10 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
     double* const zs_base = lds.zs;
 
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+#ifdef SX_STAMPS
+        const unsigned long long tile_t0 = stamp();
+        unsigned long long first_k = 0, first_kb = 0;
+#endif
         const int e = tile / tiles_per_problem;
         const int c0 = (tile - e * tiles_per_problem) * SX_TILE;  // first particle of the tile within problem e
         const bool valid = owner && (c0 + tid < rp.P);
@@ -446,6 +488,9 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
         // ---- the sampling distribution and this tile's action sequences (as cem_rollout_kernel's prologue) ----
         const double* dist_mean = rp.mean + (int64_t)e * H * NU;
         const double* dist_std = rp.std + (int64_t)e * H * NU;
+        // (requesting the first noise draw or the start state here, ahead of the refit, as cem_rollout_kernel does: 12 to 23
+        // spilled dwords in the step loop and 1.2 % slower; not done)
+        bool have_q = rp.q0 != nullptr;
         if (rp.elite_rows) {
             const int L = H * NU, W = 2 + L;
             double* const ms = lds.kfrag;   // [2][L]: the Kstar buffer is free until the first step
@@ -489,7 +534,6 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
         // Per-particle state in LDS.  st[b][c] = (p, Q, var) -- two buffers: the state after step s (p_{s+1}, Q_{s+1}, with the
         // predictive variance of step s) lives in buffer (s + 1) & 1, so the wave that advances the state and the wave that
         // prices the previous step never touch the same row in one phase.  ac[c] = (objective cost, constraint cost, status).
-        bool have_q = rp.q0 != nullptr;
         const bool lane_owner = lane < SX_TILE;                 // (waves 0 and 4 both run per-particle code on lanes 0..15)
         const bool lane_valid = lane_owner && (c0 + lane < rp.P);
         auto st_row = [&](int buf, int c) { return pq + (buf * SX_TILE + c) * PQS; };
@@ -516,7 +560,10 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
         }
         __syncthreads();
 
-        if (!SX_RH_WFIRST && tile == (int)blockIdx.x) {     // the first tile of this workgroup: now request the resident W
+        // The first tile of this workgroup requests the resident W (272 KB per workgroup through a vector memory path that
+        // takes 64 bytes per cycle: 4.3k cycles).  Letting waves 4 .. 7 run their share of the first Kstar phase first and
+        // request theirs behind it changed nothing measurable (121.3-121.7 against 121.5-121.7 us, one box).
+        if (!SX_RH_WFIRST && tile == (int)blockIdx.x) {
             const v2d* __restrict__ const ap = reinterpret_cast<const v2d*>(gc.a_pack) + lane;
             if constexpr (LDSP > 0) {
                 const __amdgpu_buffer_rsrc_t arsrc =
@@ -775,7 +822,7 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
             const unsigned long long t2 = stamp();
 #endif
             const v2d* wl = wlds + wave * LDSP * 64;
-#if SX_RH_PRIO
+#if SX_RH_PRIO == 1
             // Two waves of a SIMD that take turns on the matrix pipe switch its accumulator with every instruction (67 instead
             // of 64.5 cycles per MFMA, tools/mfma_probe3.hip): the first four waves get the pipe whenever they are ready, their
             // partners fill the gaps and run alone afterwards.
@@ -791,8 +838,10 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
                 case 6: rh_mfma_phase<NS, D, NRB, 6, REGP, LDSP>(gc, lds, wl, lane, wreg); break;
                 default: rh_mfma_phase<NS, D, NRB, 7, REGP, LDSP>(gc, lds, wl, lane, wreg); break;
             }
-#if SX_RH_PRIO
+#if SX_RH_PRIO == 1
             if (wave < 4) __builtin_amdgcn_s_setprio(0);
+#elif SX_RH_PRIO == 2
+            __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef SX_STAMPS
             const unsigned long long t3 = stamp();
@@ -801,24 +850,27 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
 #ifdef SX_STAMPS
             const unsigned long long t4 = stamp();
             c_k += t1 - t0; c_kb += t2 - t1; c_m += t3 - t2; c_mb += t4 - t3;
+            if (t == 0) { first_k = t1 - t0; first_kb = t2 - t1; }
 #endif
         }
 #ifdef SX_STAMPS
+        const unsigned long long loop_t1 = stamp();
         if (rp.stamps && lane == 0 && tile == (int)blockIdx.x) {
             unsigned long long* o = rp.stamps + ((size_t)blockIdx.x * nw + wave) * 8;
-            o[0] = c_k; o[1] = c_kb; o[2] = c_m; o[3] = c_mb; o[4] = 0; o[5] = 0;
+            o[0] = c_k; o[1] = c_kb; o[2] = c_m; o[3] = c_mb;
+            o[4] = (ct0 - tile_t0) | (first_k << 32);   // prologue | the first step's Kstar phase
             unsigned long long rt1;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
             o[6] = stamp() - ct0;   // shader cycles of the step loop
             o[7] = rt1 - rt0;       // the same span in 10 ns ticks
         }
 #endif
-        // the last step's state, then the two steps whose costs are still open (wave 0 itself: in program order)
-        if (wave == 0) {
-            if (owner) finish_state(H - 1);
-            if (H > 1) finish_costs(H - 2);
-            finish_costs(H - 1);
-        }
+        // the last step's state on wave 0 while wave 4 closes the costs of step H - 2 beside it (they read the other state
+        // buffer), then the last step's costs (the cost sums are read-modify-write: after wave 4's, hence the barrier)
+        if (wave == 0 && owner) finish_state(H - 1);
+        if (wave == 4 && H > 1) finish_costs(H - 2);
+        __syncthreads();
+        if (wave == 0) finish_costs(H - 1);
         if (valid) {
             const int64_t g = (int64_t)e * rp.P + c0 + tid;
             rp.obj_cost[g] = ac_row[0];
@@ -827,6 +879,10 @@ __global__ __launch_bounds__(kRhThreads) void cem_rollout_rh_kernel(GpConst<NS, 
             if (st) atomicOr(rp.status, st);
         }
         __syncthreads();   // the next tile's prologue reuses the Kstar buffer and the action table
+#ifdef SX_STAMPS
+        if (rp.stamps && lane == 0 && tile == (int)blockIdx.x)   // epilogue | the first step's wait at the barrier (W arriving)
+            rp.stamps[((size_t)blockIdx.x * nw + wave) * 8 + 5] = (stamp() - loop_t1) | (first_kb << 32);
+#endif
     }
 }
 

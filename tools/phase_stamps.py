@@ -33,7 +33,7 @@ for _ in range(3):
     cem_rollout(ssm, env, x0, H, mean=mean, std=std, noise=noise)
 torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(nwg, nw, 8).astype(np.float64)
-s = raw[:, :, :4] / H   # (slots 4, 5: a third phase that no longer exists)
+s = raw[:, :, :4] / H
 clk = np.median(raw[:, 0, 6] / (raw[:, 0, 7] * 10.0))
 print(f'shader clock while the kernel runs: {clk:.2f} GHz (s_memtime cycles per s_memrealtime tick; all {nwg} workgroups resident)')
 names = ['kstar', 'kstar->barrier', 'mfma', 'mfma->barrier']
@@ -41,3 +41,12 @@ print(f'cycles per step (median over {nwg} workgroups), per wave:')
 for w in range(nw):
     med = np.median(s[:, w, :], axis=0)
     print(f'  wave {w}: ' + '  '.join(f'{n}={v:8.0f}' for n, v in zip(names, med)) + f'   total={med.sum():8.0f}')
+if os.environ.get('SX_ROLLOUT', 'rh') == 'rh' and raw[:, :, 4].any():
+    # the 8-wave form packs the launch's fixed parts into slots 4 and 5: prologue | first step's Kstar phase, epilogue | first
+    # step's wait before its first barrier (the resident W arriving)
+    i4, i5 = buf.cpu().numpy().reshape(nwg, nw, 8)[:, :, 4], buf.cpu().numpy().reshape(nwg, nw, 8)[:, :, 5]
+    lo, hi = (lambda a: np.median(a & 0xffffffff, axis=0)), (lambda a: np.median(a >> 32, axis=0))
+    print('fixed parts of the launch (cycles, median over workgroups), per wave:')
+    for w in range(nw):
+        print(f'  wave {w}: prologue={lo(i4)[w]:8.0f}  first kstar={hi(i4)[w]:8.0f}  first kstar->barrier={hi(i5)[w]:8.0f}  '
+              f'epilogue={lo(i5)[w]:8.0f}  step loop={np.median(raw[:, w, 6]):9.0f}')

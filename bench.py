@@ -100,9 +100,9 @@ def mlp_flops_per_particle_step(widths, d_in, n_s, n_out, members):
 
 
 # the kernel classes the roofline object can be about (the fused rollout of the GP / degenerate-kernel / MC-dropout models)
-# (SX_PROF_ROLLOUT_FUSED, SX_PROF_ROLLOUT_FEAT, SX_PROF_ROLLOUT_MLP of include/sx_amd.h)
-DOMINANT_KINDS = (0, 5, 6)
-DOMINANT_KERNELS = ('cem_rollout_kernel', 'cem_rollout_feat_kernel', 'cem_rollout_mlp_kernel')
+# (SX_PROF_ROLLOUT_FUSED, SX_PROF_TRMM_BIG, SX_PROF_ROLLOUT_FEAT, SX_PROF_ROLLOUT_MLP of include/sx_amd.h)
+DOMINANT_KINDS = (0, 3, 5, 6)
+DOMINANT_KERNELS = ('cem_rollout_kernel', 'trmm_reduce_kernel', 'cem_rollout_feat_kernel', 'cem_rollout_mlp_kernel')
 
 
 def PROFILE_STRIDE(cfg, launches=None):

@@ -307,8 +307,7 @@ class FusedCemMpc:
         self._device = torch.device(device if device is not None else 'cuda:0')
         self._init_std = self._init_std.to(self._device)
         # the iteration's collective on the compute stream (our own RCCL communicator) where the group is an nccl one
-        self._comm = (distributed.RcclComm(process_group, self._device)
-                      if self._sharded and distributed.RcclComm.wanted(process_group, self._device) else None)
+        self._comm = distributed.make_comm(process_group, self._device) if self._sharded else None
         self._gen = torch.Generator(device=self._device)
         self._gen.manual_seed(distributed.rank_seed(seed, self._rank))
         self.last_status = 0

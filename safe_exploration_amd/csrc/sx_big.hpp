@@ -166,21 +166,28 @@ __global__ __launch_bounds__(256) void kstar_big_kernel(GpConst<NS, D> gc, BigWs
 // every workgroup reading ONE W tile and ONE Kstar tile (no fabric traffic at all) the times are the same: the kernel is
 // bound by MFMA issue and by how evenly the tiles pack, not by HBM (8 - 11 GB per launch at ~2 TB/s).
 // PPC = fragment pairs per K-chunk (1 or 2: 8 or 16 k), NBUF = LDS buffers (NBUF - 1 chunks of DMA in flight).
-template <int PPC, int NBUF>
-constexpr int big_lds_bytes() { return NBUF * 2 * kBigRb * PPC * 64 * 16; }   // [buffer][W | Kstar][block][pair][lane] x 16 B
+// PT = particle tiles (of 16) per workgroup: 8 (128 rows x 128 particles), or 4 for small grids -- twice the workgroups, so that
+// a grid of one round of 128 x 128 tiles (N ~ 1000 at 4096 particles: ONE workgroup of 4 waves per compute unit, every
+// barrier and DMA wait idling its SIMDs) becomes two workgroups per compute unit that fill each other's gaps.
+template <int PPC, int NBUF, int PT = kBigRb>
+constexpr int big_lds_bytes() { return NBUF * (kBigRb + PT) * PPC * 64 * 16; }   // [buffer][W blocks | Kstar tiles][pair][lane] x 16 B
 
-template <int NS, int D, int PPC, int NBUF>
+template <int NS, int D, int PPC, int NBUF, int PT>
 __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <= 4 ? 2 : 1)) void trmm_reduce_kernel(GpConst<NS, D> gc, BigWs ws, int64_t p128,
                                                                       int row_tiles, int xcd_aware) {
+    static_assert(PT == 8 || PT == 4, "a wave column holds PT / 2 particle tiles");
+    constexpr int NT = PT / 2;                                // particle tiles per wave column
     extern __shared__ __attribute__((aligned(16))) double big_smem[];
     typedef __attribute__((address_space(3))) v2d lds_v2d;
-    lds_v2d* const lds = (lds_v2d*)big_smem;                 // [NBUF][2][8][PPC][64]
-    constexpr int kFrags = kBigRb * PPC;                      // fragments of one operand per chunk
-    constexpr int kPieces = 2 * kFrags / 4;                   // DMA pieces per wave and chunk
+    lds_v2d* const lds = (lds_v2d*)big_smem;                 // [NBUF][8 W blocks + PT Kstar tiles][PPC][64]
+    constexpr int kFragsW = kBigRb * PPC, kFragsK = PT * PPC;   // fragments of the two operands per chunk
+    constexpr int kFragsBuf = kFragsW + kFragsK;
+    constexpr int kPiecesW = kFragsW / 2, kPiecesK = kFragsK / 2;   // DMA pieces per wave and chunk (waves 0, 1: W; 2, 3: Kstar)
+    constexpr int kPieces = kPiecesW;                         // (the larger of the two: array bound)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int pgroups = (int)(p128 / kBigTile);
+    const int pgroups = (int)(p128 / (PT * 16));
     // XCD-aware decode (see above); any grid whose size is not a multiple of 8 keeps the plain order
     int id = blockIdx.x;
     const int total = gridDim.x;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <=
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(gc.a_pack) + (int64_t)d * wpo * 128, 0, (int)(wpo * 1024), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
-        ws.ks + (((int64_t)d * (p128 / 16) + (int64_t)pg_src * kBigRb) * tstride) * 2, 0, (int)(kBigRb * tstride * 16), 0x00020000);
+        ws.ks + (((int64_t)d * (p128 / 16) + (int64_t)pg_src * PT) * tstride) * 2, 0, (int)(PT * tstride * 16), 0x00020000);
     const bool is_k = wave >= 2;
     const int lane16 = lane * 16;
   for (int rep = 0; rep < 2; ++rep) {
@@ -236,46 +243,51 @@ __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <=
     int piece_off[kPieces];     // byte offset of the fragment at q0 = 0 (SGPRs)
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
-        const int f = kPieces * (wave & 1) + i, blk = f / PPC, pr = f % PPC;
+        const int f = (is_k ? kPiecesK : kPiecesW) * (wave & 1) + i, blk = f / PPC, pr = f % PPC;
         const int rb = rt_src * kBigRb + blk;
         piece_off[i] = is_k ? (int)((blk * tstride + pr * 64) * 16) : (rb * (rb + 1) + pr) * 1024;
     }
+    // (ONE loop with the piece count tested inside: written as two loops under `if (is_k) ... else ...`, the host compiler
+    // of ROCm 7.2 silently emitted no launch stub for this kernel -- the library then failed to load with an undefined
+    // symbol; tests/test_abi.py loads it on the CPU and catches that)
     auto issue_chunk = [&](int chunk, int buf) {
 #pragma unroll
         for (int i = 0; i < kPieces; ++i) {
-            const int f = kPieces * (wave & 1) + i;
-            lds_v2d* dst = lds + ((buf * 2 + (is_k ? 1 : 0)) * kFrags + f) * 64;      // 1 KB per fragment
-            const int soff = piece_off[i] + chunk * (PPC * 1024);
-            if (is_k)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (__attribute__((address_space(3))) void*)dst, 16, lane16, soff, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)dst, 16, lane16, soff, 0, 0);
+            if (i < (is_k ? kPiecesK : kPiecesW)) {
+                const int f = (is_k ? kPiecesK : kPiecesW) * (wave & 1) + i;
+                lds_v2d* dst = lds + (buf * kFragsBuf + (is_k ? kFragsW : 0) + f) * 64;      // 1 KB per fragment
+                const int soff = piece_off[i] + chunk * (PPC * 1024);
+                if (is_k)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (__attribute__((address_space(3))) void*)dst, 16, lane16, soff, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)dst, 16, lane16, soff, 0, 0);
+            }
         }
     };
 
-    v4d acc[4][4];
+    v4d acc[4][NT];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        for (int n = 0; n < NT; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
 
     auto compute = [&](int chunk, int buf) {
-        const lds_v2d* sa = lds + (buf * 2 + 0) * kFrags * 64 + lane;
-        const lds_v2d* sb = lds + (buf * 2 + 1) * kFrags * 64 + lane;
+        const lds_v2d* sa = lds + buf * kFragsBuf * 64 + lane;
+        const lds_v2d* sb = lds + (buf * kFragsBuf + kFragsW) * 64 + lane;
 #pragma unroll
         for (int pr = 0; pr < PPC; ++pr) {
-            v2d a[4], b[4];
+            v2d a[4], b[NT];
 #pragma unroll
             for (int m = 0; m < 4; ++m) a[m] = sa[((4 * wr + m) * PPC + pr) * 64];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = sb[((4 * wc + n) * PPC + pr) * 64];
+            for (int n = 0; n < NT; ++n) b[n] = sb[((NT * wc + n) * PPC + pr) * 64];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 // beyond the diagonal of row-block rb0 + 4 wr + m its W fragments are not its own: nothing to add
                 // (wave-uniform; only the last chunks of a tile's K extent are affected)
                 if (chunk * PPC + pr >= 2 * (rb0 + 4 * wr + m + 1)) continue;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
+                for (int n = 0; n < NT; ++n) {
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
                 }
@@ -294,9 +306,13 @@ __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <=
         constexpr int BUF = decltype(bufc)::value;
         // outstanding after this wait: the pieces of the chunks younger than c that have been issued
         const int younger = (nchunks - 1 - c) < (NBUF - 2) ? (nchunks - 1 - c) : (NBUF - 2);
-        if (younger >= 1 && NBUF >= 3)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
-        else
+        if (younger >= 1 && NBUF >= 3) {
+            // (counted wait: this wave's pieces of ONE younger chunk may stay in flight)
+            if (is_k)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesK) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPiecesW) : "memory");
+        } else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -311,8 +327,8 @@ __global__ __launch_bounds__(kBigThreads, (PPC * NBUF <= 3) ? 3 : (PPC * NBUF <=
     }
     // epilogue: rows < N are squared and summed, rows N .. N + D are the mean / Jacobian rows
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int64_t p = ((int64_t)pg * kBigRb + 4 * wc + n) * 16 + (lane & 15);
+    for (int n = 0; n < NT; ++n) {
+        const int64_t p = ((int64_t)pg * PT + NT * wc + n) * 16 + (lane & 15);
         double s = 0.0;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {

@@ -454,12 +454,16 @@ static int launch_polytope(const sx_env* env, int P, const double* p, const doub
 // memory-bound, its tiles differ 16-fold in work and the tail of the launch was what it lost.
 static const int g_trmm_order = std::getenv("SX_TRMM_ORDER") ? std::atoi(std::getenv("SX_TRMM_ORDER")) : -1;
 static const int g_trmm_variant = std::getenv("SX_TRMM_VARIANT") ? std::atoi(std::getenv("SX_TRMM_VARIANT")) : 13;
+//   SX_TRMM_PT      = particle tiles per workgroup: 8 | 4 (default: 4 where 8 would leave a compute unit with at most two
+//                     workgroups, see launch_trmm)
+static const int g_trmm_pt = std::getenv("SX_TRMM_PT") ? std::atoi(std::getenv("SX_TRMM_PT")) : 0;
 
-template <int NS, int D, int PPC, int NBUF>
+template <int NS, int D, int PPC, int NBUF, int PT>
 static void launch_trmm_v(int kind, const GpConst<NS, D>& gc, const BigWs& ws, int64_t p128, int row_tiles, hipStream_t stream) {
-    constexpr int lds = big_lds_bytes<PPC, NBUF>();
-    (void)allow_lds(trmm_reduce_kernel<NS, D, PPC, NBUF>, lds);
-    const int64_t tiles = (p128 / kBigTile) * row_tiles * NS;
+    constexpr int lds = big_lds_bytes<PPC, NBUF, PT>();
+    (void)allow_lds(trmm_reduce_kernel<NS, D, PPC, NBUF, PT>, lds);
+    const int64_t pgroups = p128 / (PT * 16);
+    const int64_t tiles = pgroups * row_tiles * NS;
     // Tile order.  A large grid runs longest tile first.  A grid of a few rounds is all quantisation: it runs PAIRED tiles
     // (row tile rt and row_tiles - 1 - rt in one workgroup: equal work) when that deals the work out more evenly than
     // longest-first does -- judged by dealing the workgroups round-robin onto the 256 CUs and comparing the fullest CU.
@@ -468,7 +472,7 @@ static void launch_trmm_v(int kind, const GpConst<NS, D>& gc, const BigWs& ws, i
     if (order < 0) {
         order = 8;
         if (tiles <= 3 * 768 && row_tiles > 1) {
-            const int nrb = gc.n_pad >> 4, groups = (int)(p128 / kBigTile) * NS;
+            const int nrb = gc.n_pad >> 4, groups = (int)pgroups * NS;
             std::vector<double> work(row_tiles);
             for (int rt = 0; rt < row_tiles; ++rt) {
                 const int rb0 = rt * kBigRb, rb_end = rb0 + kBigRb < nrb ? rb0 + kBigRb : nrb;
@@ -490,21 +494,27 @@ static void launch_trmm_v(int kind, const GpConst<NS, D>& gc, const BigWs& ws, i
             if (fullest(paired) < fullest(plain)) order = 16;
         }
     }
-    const dim3 grid((unsigned)((order & 16) ? (p128 / kBigTile) * ((row_tiles + 1) / 2) * NS : tiles));
+    const dim3 grid((unsigned)((order & 16) ? pgroups * ((row_tiles + 1) / 2) * NS : tiles));
     if (kind >= 0)
-        launch(kind, trmm_reduce_kernel<NS, D, PPC, NBUF>, grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles, order);
+        launch(kind, trmm_reduce_kernel<NS, D, PPC, NBUF, PT>, grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles, order);
     else
-        hipLaunchKernelGGL((trmm_reduce_kernel<NS, D, PPC, NBUF>), grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles,
+        hipLaunchKernelGGL((trmm_reduce_kernel<NS, D, PPC, NBUF, PT>), grid, dim3(kBigThreads), lds, stream, gc, ws, p128, row_tiles,
                            order);
 }
 
 template <int NS, int D>
 static void launch_trmm(int kind, const GpConst<NS, D>& gc, const BigWs& ws, int64_t p128, int row_tiles, hipStream_t stream) {
+    // Small grids take 128 x 64 tiles: with 128 x 128 a grid of up to two workgroups per compute unit (N ~ 1000 .. 1400 at
+    // 4096 particles) leaves each SIMD one or two waves that idle through every barrier and DMA wait; twice the workgroups
+    // at half the size fill those gaps (tools/n_sweep.sh: the step at the path switch).
+    const int64_t wgs8 = (p128 / kBigTile) * row_tiles * NS;
+    const bool half = g_trmm_pt ? g_trmm_pt == 4 : wgs8 <= 2 * 768;
+    if (half) return launch_trmm_v<NS, D, 1, 3, 4>(kind, gc, ws, p128, row_tiles, stream);
     switch (g_trmm_variant) {
-        case 12: return launch_trmm_v<NS, D, 1, 2>(kind, gc, ws, p128, row_tiles, stream);
-        case 22: return launch_trmm_v<NS, D, 2, 2>(kind, gc, ws, p128, row_tiles, stream);
-        case 23: return launch_trmm_v<NS, D, 2, 3>(kind, gc, ws, p128, row_tiles, stream);
-        default: return launch_trmm_v<NS, D, 1, 3>(kind, gc, ws, p128, row_tiles, stream);
+        case 12: return launch_trmm_v<NS, D, 1, 2, 8>(kind, gc, ws, p128, row_tiles, stream);
+        case 22: return launch_trmm_v<NS, D, 2, 2, 8>(kind, gc, ws, p128, row_tiles, stream);
+        case 23: return launch_trmm_v<NS, D, 2, 3, 8>(kind, gc, ws, p128, row_tiles, stream);
+        default: return launch_trmm_v<NS, D, 1, 3, 8>(kind, gc, ws, p128, row_tiles, stream);
     }
 }
 

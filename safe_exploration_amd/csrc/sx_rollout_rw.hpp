@@ -46,6 +46,9 @@
 #ifndef SX_RW_PF
 #define SX_RW_PF 2         // Kstar fragment pairs in flight ahead of the MFMAs that consume them (3 spills at n_pad = 208)
 #endif
+#ifndef SX_RW_POLYFOLD
+#define SX_RW_POLYFOLD 0   // the cubic in w = r / u with the unit folded into its coefficients (one VALU instruction less per value)
+#endif
 #ifndef SX_RW_DIET
 #define SX_RW_DIET 1       // Kstar phase with the expanded exponent, the 2048-entry table and no all-padding pairs (rw_kstar_phase)
 #endif
@@ -363,16 +366,27 @@ __device__ __forceinline__ void rw_kstar_phase(const GpConst<NS, D>& gc, const R
 #pragma unroll
         for (int i = 0; i < M; ++i) s.t[i] = etab[s.mi[i] & emask];
 #pragma unroll
+#if SX_RW_POLYFOLD
+        for (int i = 0; i < M; ++i) s.p[i] = yc[i] - m[i];   // w = r / u, exact
+#else
         for (int i = 0; i < M; ++i) s.p[i] = (yc[i] - m[i]) * kExpUnit2;   // r (the difference is exact)
+#endif
     };
     auto stage_a2 = [&](Set& s) {
         double r[M];
 #pragma unroll
         for (int i = 0; i < M; ++i) r[i] = s.p[i];
 #pragma unroll
+#if SX_RW_POLYFOLD
+        // exp(u w) - 1 = w (u + w (u^2/2 + w u^3/6)): the unit folded into the coefficients, one multiplication less
+        for (int i = 0; i < M; ++i) s.p[i] = fma(r[i], kExpUnit2 * kExpUnit2 * kExpUnit2 / 6.0, kExpUnit2 * kExpUnit2 * 0.5);
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.p[i] = fma(s.p[i], r[i], kExpUnit2);
+#else
         for (int i = 0; i < M; ++i) s.p[i] = fma(r[i], 1.66666666666666666667e-01, 0.5);
 #pragma unroll
         for (int i = 0; i < M; ++i) s.p[i] = fma(s.p[i], r[i], 1.0);
+#endif
 #pragma unroll
         for (int i = 0; i < M; ++i) s.p[i] = s.p[i] * r[i];
     };

@@ -99,6 +99,28 @@ class RcclComm:
                                                  self._comm, self._stream()), 'ncclAllReduce')
 
 
+def make_comm(group, device) -> Optional[RcclComm]:
+    """The direct RCCL communicator for `group`, or None (then the exchange goes through torch.distributed).  Collective: if
+    ANY rank fails to create its communicator -- a second rank on the same device, no usable bootstrap interface -- every
+    rank drops to torch's path together (one all-reduce of a flag over the existing group) and rank 0 says so once."""
+    if not RcclComm.wanted(group, device):
+        return None
+    comm, err = None, ''
+    try:
+        comm = RcclComm(group, device)
+    except Exception as exc:   # noqa: BLE001
+        err = str(exc)
+    flag = torch.tensor([0 if comm is not None else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()) != 0:
+        if dist.get_rank(group) == 0:
+            import sys
+            print(f'safe_exploration_amd: direct RCCL communicator not available ({err or "another rank failed"}); '
+                  f'the elite exchange uses torch.distributed', file=sys.stderr)
+        return None
+    return comm
+
+
 def world_and_rank(group=None) -> Tuple[int, int]:
     if group is None:
         return 1, 0   # sharding is opt-in: pass the group (e.g. dist.group.WORLD) explicitly

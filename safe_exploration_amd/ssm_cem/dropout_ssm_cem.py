@@ -122,6 +122,7 @@ class McDropoutSSM(CemSSM):
         self._seed = int(getattr(conf, 'mc_dropout_seed', 0))
         self._gen = torch.Generator(device=self._device)
         self._gen.manual_seed(self._seed)
+        self._constructs = 0
         self._model = self._construct()
         self._last_training_losses: List[float] = []
         self._mlp: Optional[_lib.SxMlpModel] = None
@@ -129,8 +130,11 @@ class McDropoutSSM(CemSSM):
         self._freeze()
 
     def _construct(self) -> _DropoutNet:
+        # (seeded, and a different seed every time: mc_dropout_reinitialize constructs the network again before each
+        # training and must not get the same weights back -- reference dropout_ssm_cem.py:115-117, test_ssm_cem.py:66-86)
         state = torch.random.get_rng_state()
-        torch.manual_seed(self._seed)
+        torch.manual_seed(self._seed + self._constructs)
+        self._constructs += 1
         out_features = self.num_states * 2 if self._predict_std else self.num_states
         net = _DropoutNet(self.num_states + self.num_actions, out_features, self._hidden, self._rate,
                           self._type == 'concrete', self._on_input).to(torch.float64).to(self._device)
@@ -239,12 +243,18 @@ class McDropoutSSM(CemSSM):
             optimizer.step()
             losses.append(float(loss.item()))
         self._last_training_losses = losses
-        self._freeze()
+        if self._training_iterations > 0 or self._reinitialize_on_train:
+            self._freeze()      # (nothing trained, nothing constructed: the frozen ensemble stands)
 
     def collect_metrics(self) -> Dict[str, Any]:
+        """The dropout rate of every dropout layer under the reference's key: `dropout_p_layer_<i>` with i the layer's index in
+        bnn's module list ([input dropout,] then (linear, dropout, relu) per hidden layer) -- 1, 4, 7, ... without input
+        dropout, 0, 2, 5, 8, ... with it (reference dropout_ssm_cem.py:175-181, test_ssm_cem.py:88-108)."""
         ps = self._model.rates().detach().cpu()
-        first = 0 if self._on_input else 1
-        return {f'dropout_p_layer_{i}': float(ps[i]) for i in range(first, len(ps))}
+        shift = 1 if self._on_input else 0
+        out = {'dropout_p_layer_0': float(ps[0])} if self._on_input else {}
+        out.update({f'dropout_p_layer_{1 + 3 * (i - 1) + shift}': float(ps[i]) for i in range(1, len(ps))})
+        return out
 
     @property
     def parametric(self) -> bool:

@@ -87,6 +87,42 @@ def test_ensemble_posterior_vs_oracle(kw, n_s, n_u):
     assert isinstance(ssm.collect_metrics(), dict)
 
 
+def test_collect_metrics_keys_are_the_references(mlp_path):   # test_ssm_cem.py:88-108, test_gal_concrete_dropout.py:18-27
+    if mlp_path == 'valu':
+        pytest.skip('host logic: one run covers it')
+    from safe_exploration_amd.ssm_cem.dropout_ssm_cem import McDropoutSSM
+    from safe_exploration_amd.ssm_cem.gal_concrete_dropout import GalConcreteDropoutSSM
+    ssm = McDropoutSSM(conf(mc_dropout_hidden_features=[2, 2, 10, 2], mc_dropout_on_input=False), 2, 1)
+    assert ssm.collect_metrics().keys() == {'dropout_p_layer_1', 'dropout_p_layer_4', 'dropout_p_layer_7', 'dropout_p_layer_10'}
+    ssm = McDropoutSSM(conf(mc_dropout_hidden_features=[2, 2, 10, 2], mc_dropout_on_input=True), 2, 1)
+    assert ssm.collect_metrics().keys() == {'dropout_p_layer_0', 'dropout_p_layer_2', 'dropout_p_layer_5', 'dropout_p_layer_8',
+                                            'dropout_p_layer_11'}
+    gal = GalConcreteDropoutSSM(conf(mc_dropout_hidden_features=[3, 2], mc_dropout_type='concrete', mc_dropout_on_input=True,
+                                     mc_dropout_predict_std=True), 3, 2)
+    assert len([k for k in gal.collect_metrics() if k.startswith('dropout_p')]) == 4
+
+
+@pytest.mark.parametrize('reinitialize', [False, True])
+def test_update_model_reinitialize_on_train(mlp_path, reinitialize):   # test_ssm_cem.py:44-86
+    """With 0 training iterations update_model leaves the weights alone unless mc_dropout_reinitialize is set: then the
+    network is constructed again (different weights, different predictions)."""
+    if mlp_path == 'valu':
+        pytest.skip('host logic: one run covers it')
+    from safe_exploration_amd.ssm_cem.dropout_ssm_cem import McDropoutSSM
+    kw = dict(mc_dropout_hidden_features=[2, 2], mc_dropout_type='concrete', mc_dropout_predict_std=True,
+              mc_dropout_reinitialize=reinitialize, mc_dropout_training_iterations=0)
+    states, actions = T(np.ones((3, 2))), T(np.ones((3, 1)))
+    torch.manual_seed(1)
+    mean1, _ = McDropoutSSM(conf(**kw), 2, 1).predict_without_jacobians(states, actions)
+    torch.manual_seed(1)
+    ssm = McDropoutSSM(conf(**kw), 2, 1)
+    ssm.update_model(torch.empty((0, 3), dtype=torch.float64, device=DEV), torch.empty((0, 2), dtype=torch.float64, device=DEV),
+                     opt_hyp=True)
+    mean2, var2 = ssm.predict_without_jacobians(states, actions)
+    assert tuple(mean2.shape) == (3, 2) and tuple(var2.shape) == (3, 2)
+    assert torch.allclose(mean1, mean2) == (not reinitialize)
+
+
 def test_rollout_solve_and_get_action_over_the_ensemble():
     from safe_exploration_amd import problems
     from safe_exploration_amd.cem_mpc import FusedCemMpc, cem_rollout

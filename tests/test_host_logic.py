@@ -356,6 +356,41 @@ class TestJunkDimensionsSSM:   # test_ssm_cem.py:116-168
             ssm.predict_raw(torch.empty((3, 4)))
 
 
+def test_junk_dimensions_fold_when_the_padded_sizes_are_beyond_the_inner_models_limits():
+    """An inner model that refuses the padded sizes (ValueError, as GpCemSSM does beyond n_s 4 / n_u 2) is built over the
+    padded columns that are ever non-zero -- training rows fill columns 0 .. n_s + n_u, queries 0 .. n_s and n_s + J ..
+    n_s + J + n_u -- with the real outputs only, if it is an RBF exact GP; anything else re-raises the refusal."""
+    from safe_exploration_amd.ssm_cem.ssm_cem import JunkDimensionsSSM
+    inner = mock.Mock()
+    inner.kernel_family = 'rbf'
+    inner.predict_with_jacobians.return_value = (torch.empty((3, 2)), torch.empty((3, 2)), torch.empty((3, 2, 4)))
+    inner.predict_raw.return_value = (torch.empty((1, 2)), torch.empty((1, 2)))
+
+    def constructor(state_dimen, action_dimen):
+        if state_dimen > 4 or action_dimen > 2:
+            raise ValueError('beyond the compiled limits')
+        assert (state_dimen, action_dimen) == (2, 2)
+        return inner
+
+    ssm = JunkDimensionsSSM(constructor, state_dimen=2, action_dimen=1, junk_states=5, junk_actions=3)
+    assert ssm.folded_columns == (0, 1, 2, 7)
+    states, actions = torch.tensor([[1., 2.]] * 3), torch.tensor([[3.]] * 3)
+    means, variances, jacs = ssm.predict_with_jacobians(states, actions)
+    assert means.size() == (3, 2) and jacs.size() == (3, 2, 3)
+    (call_states, call_actions), _ = inner.predict_with_jacobians.call_args
+    assert torch.equal(call_states, states) and torch.equal(call_actions, torch.tensor([[0., 3.]] * 3))   # [train-only, query-only]
+    ssm.update_model(torch.tensor([[1., 2., 3.]] * 4), torch.ones((4, 2)), opt_hyp=False, replace_old=True)
+    x, y = inner.update_model.call_args[0][:2]
+    assert torch.equal(x, torch.tensor([[1., 2., 3., 0.]] * 4)) and y.size() == (4, 2)
+    ssm.predict_raw(torch.tensor([[1., 2., 3.]]))
+    assert torch.equal(inner.predict_raw.call_args[0][0], torch.tensor([[1., 2., 3., 0.]]))     # raw inputs pad like training rows
+    inner.kernel_family = 'feature'
+    with pytest.raises(ValueError, match='compiled limits'):
+        JunkDimensionsSSM(constructor, state_dimen=2, action_dimen=1, junk_states=5, junk_actions=0)
+    with pytest.raises(ValueError, match='compiled limits'):      # two actions: the fold needs 4 action columns
+        JunkDimensionsSSM(constructor, state_dimen=2, action_dimen=2, junk_states=5, junk_actions=0)
+
+
 def test_solver_draws_noise_for_several_solves_at_once_and_pools_status_words():
     """Host bookkeeping of FusedCemMpc that needs no GPU: the standard normals of up to 8 solves come from ONE generator
     launch (distinct slices, redrawn when the pool is used up or the episode count changes), the status words are slices of

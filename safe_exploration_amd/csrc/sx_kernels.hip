@@ -625,16 +625,19 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
                         (size_t)SX_TILE * rp.H * NU) * sizeof(double);
     const int tiles = (rp.P + SX_TILE - 1) / SX_TILE;
     if (all_at_once) {
-        // Three forms of the kernel: W partly resident on 8 waves (sx_rollout_rh.hpp: the default
-        // where it is instantiated, n_s <= 2), all of W in the registers of 4 waves (sx_rollout_rw.hpp: on request only --
-        // it does not beat the streaming kernel at one tile per compute unit), W streamed from L2 (cem_rollout_kernel: any
-        // size that fits the LDS).  SX_ROLLOUT=rh|rw|stream picks one for A/B runs; SX_ROLLOUT_STRICT forbids the silent
-        // fall-back to the streaming kernel, so that a run knows what it timed.
+        // Three forms of the kernel: W partly resident on 8 waves (sx_rollout_rh.hpp: n_s <= 2), all of
+        // W in the registers of 4 waves (sx_rollout_rw.hpp: every n_s, smaller N), W streamed from L2 (cem_rollout_kernel: any
+        // size that fits the LDS).  By default the first of the three that is instantiated for the shape: the 4-wave form
+        // loses to the streaming kernel only where the 8-wave form exists (n_s = 2, n_u = 1: 126.6 against 125.7 us at config
+        // 2), and beats it by 7 - 16 % on the shapes the 8-wave form does not cover (n_s = 3, 4; n_s = n_u = 2 beyond N = 128).
+        // SX_ROLLOUT=rh|rw|stream picks ONE form for A/B runs (falling back to the streaming kernel where it is not
+        // instantiated, unless SX_ROLLOUT_STRICT is set, so that a run knows what it timed).
         static const int form = [] {
             const char* e = std::getenv("SX_ROLLOUT");
             if (e && std::strcmp(e, "stream") == 0) return 0;
             if (e && std::strcmp(e, "rw") == 0) return 1;
-            return 2;
+            if (e && std::strcmp(e, "rh") == 0) return 2;
+            return 3;
         }();
         if (form != 0) {
             static const bool strict = std::getenv("SX_ROLLOUT_STRICT") != nullptr;
@@ -642,9 +645,11 @@ static int launch_rollout(const sx_gp_model* m, const sx_env* env, const Rollout
 #ifdef SX_STAMPS
             rps.stamps = g_stamp_host;
 #endif
-            const int r = form == 2 ? launch_rollout_rh<NS, NU>(make_gp_const<NS, NU>(m, 8), rc, cc, rps, stream)
-                                    : launch_rollout_rw<NS, NU>(make_gp_const<NS, NU>(m, kRwWaves), rc, cc, rps, stream);
-            if (r != SX_ERR_UNSUPPORTED || strict) return r;
+            int r = SX_ERR_UNSUPPORTED;
+            if (form >= 2) r = launch_rollout_rh<NS, NU>(make_gp_const<NS, NU>(m, 8), rc, cc, rps, stream);
+            if (r == SX_ERR_UNSUPPORTED && form != 2)
+                r = launch_rollout_rw<NS, NU>(make_gp_const<NS, NU>(m, kRwWaves), rc, cc, rps, stream);
+            if (r != SX_ERR_UNSUPPORTED || (strict && form != 3)) return r;
         }
         if (int r = allow_lds(cem_rollout_kernel<NS, NU, false>, lds)) return r;
         launch(SX_PROF_ROLLOUT_FUSED, cem_rollout_kernel<NS, NU, false>, dim3(rp.E * tiles), dim3(kRolloutThreads), lds, stream,
@@ -1107,10 +1112,10 @@ int sx_cem_rollout_form(const sx_gp_model* model, int H) {
         return (ns > 1 && sx::fused_fits(ns, nu, model->n_train, model->n_pad, H, 1)) ? SX_FORM_BYOUT : SX_FORM_BIG;
     const char* e = std::getenv("SX_ROLLOUT");
     if (e && std::strcmp(e, "stream") == 0) return SX_FORM_STREAM;
-    const bool want_rw = e && std::strcmp(e, "rw") == 0;
+    const bool only_rw = e && std::strcmp(e, "rw") == 0, only_rh = e && std::strcmp(e, "rh") == 0;
 #define CALL(NS, NU) \
-    (want_rw ? (sx::rollout_rw_applies<NS, NU>(model->n_train, model->n_pad, H) ? SX_FORM_RW : SX_FORM_STREAM) \
-             : (sx::rollout_rh_applies<NS, NU>(model->n_train, model->n_pad, H) ? SX_FORM_RH : SX_FORM_STREAM))
+    ((!only_rw && sx::rollout_rh_applies<NS, NU>(model->n_train, model->n_pad, H)) ? SX_FORM_RH \
+     : ((!only_rh && sx::rollout_rw_applies<NS, NU>(model->n_train, model->n_pad, H)) ? SX_FORM_RW : SX_FORM_STREAM))
     SX_DISPATCH(ns, nu, CALL);
 #undef CALL
 }

@@ -1,6 +1,7 @@
 """One fused rollout per (n_s, n_u, N) on a synthetic problem, checked against the oracle, each in a child process with its
 stderr kept, stopping at the first failure.  SX_ROLLOUT=rh|rw|stream (+ SX_ROLLOUT_STRICT=1) picks the kernel form: this is
-how the suite covers the forms that are not the default.   python tools/rw_repro.py [n_s,n_u[,N] ...]"""
+how the suite covers the forms that are not the default.   python tools/rw_repro.py [n_s,n_u[,N] ...]
+TIME=1 also times one rollout of 4096 particles x 15 steps per shape (A/B of the forms on shapes no BASELINE config has)."""
 import os
 import subprocess
 import sys
@@ -48,6 +49,19 @@ np.testing.assert_array_equal(r['con_cost'][0].cpu().numpy(), ref.con_cost)
 assert int(r['status'].item()) == ref.status
 form = _lib.lib().sx_cem_rollout_form(ctypes.byref(ssm.device_model), H)
 print('matches the oracle; form', int(form), flush=True)
+if %(time)d:
+    # the same model at config-2 scale (4096 particles, H = 15): one launch, timed over 20 repeats
+    import time
+    Pt, Ht = 4096, 15
+    big = T(rng.normal(0, 0.25, size=(1, Pt, Ht, n_u)))
+    for _ in range(3):
+        cem_rollout(ssm, env, T(x0[None]), Ht, actions=big)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        cem_rollout(ssm, env, T(x0[None]), Ht, actions=big)
+    torch.cuda.synchronize()
+    print('timed: %%.1f us per rollout of 4096 particles x 15 steps; form %%d' %% ((time.perf_counter() - t0) / 20 * 1e6,
+          int(_lib.lib().sx_cem_rollout_form(ctypes.byref(ssm.device_model), Ht))), flush=True)
 '''
 
 
@@ -58,7 +72,7 @@ def main():
         ns, nu = shape[0], shape[1]
         n = shape[2] if len(shape) > 2 else 77
         env = dict(os.environ, SX_DEBUG_SYNC='1', AMD_LOG_LEVEL=os.environ.get('AMD_LOG_LEVEL', '1'))
-        p = subprocess.run([sys.executable, '-c', CHILD % dict(root=root, ns=ns, nu=nu, n=n)], capture_output=True, text=True,
+        p = subprocess.run([sys.executable, '-c', CHILD % dict(root=root, ns=ns, nu=nu, n=n, time=int(os.environ.get('TIME', '0')))], capture_output=True, text=True,
                            env=env, timeout=120)
         print(f'== n_s={ns} n_u={nu} N={n}: rc={p.returncode}')
         print(p.stdout[-600:])

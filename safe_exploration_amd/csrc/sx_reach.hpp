@@ -60,7 +60,13 @@ __device__ __forceinline__ double sym_lambda_max(double (&S)[NS][NS]) {
         const double o = 0.5 * (S[0][1] + S[1][0]);
         return 0.5 * (S[0][0] + S[1][1]) + sqrt(h * h + o * o);
     } else {
-        // cyclic Jacobi, fixed sweep count (quadratic convergence: 8 sweeps reach round-off for n <= 4)
+        // cyclic Jacobi, fixed sweep count (quadratic convergence: 8 sweeps reach round-off for n <= 4).  This is the longest
+        // dependent chain of a step for n_s >= 3 (round 3: ~20k of the 31k cycles of a cart-pole step at small N), so
+        //  * a rotation costs one sqrt, one division and one reciprocal square root: with a = a_qq - a_pp, b = 2 a_pq,
+        //    t = sgn(a) b / (|a| + sqrt(a^2 + b^2)), c = rsqrt(t^2 + 1), s = t c  (the textbook form theta = a / b,
+        //    t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), c = 1 / sqrt(t^2 + 1) is three divisions and two roots);
+        //  * for n = 4 the sweep runs in the round-robin order (0,1)(2,3) | (0,2)(1,3) | (0,3)(1,2): the two rotations of a
+        //    round touch disjoint rows and columns, so both angles come from the same matrix and their chains overlap.
 #pragma unroll
         for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -69,33 +75,58 @@ __device__ __forceinline__ double sym_lambda_max(double (&S)[NS][NS]) {
                 S[i][j] = s;
                 S[j][i] = s;
             }
+        // (c, s) of the rotation that annihilates S[p][q]; identity when it would not change anything.  Branch-free (the chains
+        // of a round's two rotations can only overlap in straight-line code): the arithmetic runs on whatever is there and
+        // a select takes the identity; `live` says whether any rotation of the sweep was a real one.
+        bool live = false;
+        auto angle = [&](int p, int q, double& c, double& sn) {
+            const double apq = S[p][q], app = S[p][p], aqq = S[q][q];
+            const bool on = fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * (fabs(app) + fabs(aqq));
+            const double a = aqq - app, b = 2.0 * apq;
+            const double t = (a < 0.0 ? -b : b) / (fabs(a) + sqrt(fma(a, a, b * b)));
+            const double cc = rsqrt(fma(t, t, 1.0));
+            c = on ? cc : 1.0;
+            sn = on ? t * cc : 0.0;
+            live = live || on;
+        };
+        auto rotate = [&](int p, int q, double c, double sn) {
+            const bool on = sn != 0.0;      // (a skipped rotation leaves every entry as it is, a NaN neighbour included)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {  // columns p, q
+                const double skp = S[k][p], skq = S[k][q];
+                S[k][p] = on ? c * skp - sn * skq : skp;
+                S[k][q] = on ? sn * skp + c * skq : skq;
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {  // rows p, q
+                const double spk = S[p][k], sqk = S[q][k];
+                S[p][k] = on ? c * spk - sn * sqk : spk;
+                S[q][k] = on ? sn * spk + c * sqk : sqk;
+            }
+        };
         for (int sweep = 0; sweep < 8; ++sweep) {
+            if constexpr (NS == 4) {
+                constexpr int kRound[3][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {0, 3, 1, 2}};
 #pragma unroll
-            for (int p = 0; p < NS - 1; ++p)
-#pragma unroll
-                for (int q = p + 1; q < NS; ++q) {
-                    const double apq = S[p][q];
-                    const double app = S[p][p], aqq = S[q][q];
-                    // skip when the rotation would not change anything
-                    if (fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * (fabs(app) + fabs(aqq))) {
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        const double c = 1.0 / sqrt(t * t + 1.0);
-                        const double s = t * c;
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) {  // columns p, q
-                            const double skp = S[k][p], skq = S[k][q];
-                            S[k][p] = c * skp - s * skq;
-                            S[k][q] = s * skp + c * skq;
-                        }
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) {  // rows p, q
-                            const double spk = S[p][k], sqk = S[q][k];
-                            S[p][k] = c * spk - s * sqk;
-                            S[q][k] = s * spk + c * sqk;
-                        }
-                    }
+                for (int r = 0; r < 3; ++r) {
+                    double c0, s0, c1, s1;
+                    angle(kRound[r][0], kRound[r][1], c0, s0);
+                    angle(kRound[r][2], kRound[r][3], c1, s1);
+                    rotate(kRound[r][0], kRound[r][1], c0, s0);
+                    rotate(kRound[r][2], kRound[r][3], c1, s1);
                 }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NS - 1; ++p)
+#pragma unroll
+                    for (int q = p + 1; q < NS; ++q) {
+                        double c, sn;
+                        angle(p, q, c, sn);
+                        rotate(p, q, c, sn);
+                    }
+            }
+            if (!live) break;       // a sweep without a real rotation: converged (every later sweep would do nothing either)
+            live = false;
         }
         double m = S[0][0];
 #pragma unroll

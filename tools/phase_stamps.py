@@ -17,7 +17,7 @@ from safe_exploration_amd import _lib, problems  # noqa: E402
 from safe_exploration_amd.cem_mpc import cem_rollout  # noqa: E402
 
 P, H = int(os.environ.get('P', 4096)), int(os.environ.get('H', 15))
-spec = problems.pendulum(n_train=int(os.environ.get('N', 200)))
+spec = getattr(problems, os.environ.get('WHICH', 'pendulum'))(n_train=int(os.environ.get('N', 200)))
 ssm, env = problems.build(spec, 'cuda:0')
 dev = torch.device('cuda:0')
 nwg, nw = (P + 15) // 16, int(os.environ.get('NW', 4))
@@ -25,7 +25,7 @@ buf = torch.zeros((nwg * nw, 8), dtype=torch.int64, device=dev)
 lib = _lib.lib()
 lib.sx_debug_set_stamps.argtypes = [ctypes.c_void_p]
 assert lib.sx_debug_set_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
-x0 = torch.tensor([[0.02, -0.03]], dtype=torch.float64, device=dev)
+x0 = torch.tensor([[0.02, -0.03, 0.01, 0.02][:spec.n_s]], dtype=torch.float64, device=dev)
 mean = torch.zeros((1, H, 1), dtype=torch.float64, device=dev)
 std = torch.full((1, H, 1), 0.1, dtype=torch.float64, device=dev)
 noise = torch.randn((1, P, H, 1), dtype=torch.float64, device=dev)

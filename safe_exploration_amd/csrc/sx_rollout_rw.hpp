@@ -587,6 +587,9 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
         // per-particle state: LDS row of thread c (tid < 16)
         bool have_q = rp.q0 != nullptr;
         double* const my = pq + (owner ? tid : 0) * PQS;
+#ifdef SX_STAMPS
+        unsigned long long c_f_collect = 0, c_f_reach = 0;
+#endif
         if (owner) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
@@ -638,8 +641,18 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
             }
             int st_step = 0;
             if (have_q) {
+#ifdef SX_STAMPS
+                const unsigned long long f0 = stamp();
+#endif
                 rw_collect<NS, D, NRB, true>(fc, lds, tid, z, mean, var, jac);
+#ifdef SX_STAMPS
+                const unsigned long long f1 = stamp();
+#endif
                 reach_ellipsoid<NS, NU>(frc, p, Q, u, mean, var, jac, p1, Q1, st_step);
+#ifdef SX_STAMPS
+                c_f_collect += f1 - f0;
+                c_f_reach += stamp() - f1;
+#endif
             } else {
                 rw_collect<NS, D, NRB, false>(fc, lds, tid, z, mean, var, jac);
                 reach_point<NS, NU>(frc, p, u, mean, var, p1, Q1, st_step);
@@ -743,6 +756,7 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
 
 #ifdef SX_STAMPS
         unsigned long long c_k = 0, c_kb = 0, c_m = 0, c_mb = 0;
+        c_f_collect = c_f_reach = 0;
         unsigned long long rt0;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
         const unsigned long long ct0 = stamp();
@@ -797,7 +811,7 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
 #ifdef SX_STAMPS
         if (rp.stamps && lane == 0 && tile == (int)blockIdx.x) {
             unsigned long long* o = rp.stamps + ((size_t)blockIdx.x * nw + wave) * 8;
-            o[0] = c_k; o[1] = c_kb; o[2] = c_m; o[3] = c_mb; o[4] = 0; o[5] = 0;
+            o[0] = c_k; o[1] = c_kb; o[2] = c_m; o[3] = c_mb; o[4] = c_f_collect; o[5] = c_f_reach;   // (finish(): collect | reachability)
             unsigned long long rt1;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
             o[6] = stamp() - ct0;   // shader cycles of the step loop

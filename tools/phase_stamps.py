@@ -50,3 +50,7 @@ if os.environ.get('SX_ROLLOUT', 'rh') == 'rh' and raw[:, :, 4].any():
     for w in range(nw):
         print(f'  wave {w}: prologue={lo(i4)[w]:8.0f}  first kstar={hi(i4)[w]:8.0f}  first kstar->barrier={hi(i5)[w]:8.0f}  '
               f'epilogue={lo(i5)[w]:8.0f}  step loop={np.median(raw[:, w, 6]):9.0f}')
+if os.environ.get('SX_ROLLOUT', 'rh') == 'rw' and raw[:, 0, 4].any():
+    # the 4-wave form stamps two sections of finish() on wave 0 (slots 4, 5): posterior assembly | reachability step
+    print('finish() on wave 0, cycles per step: collect = %.0f   reach_ellipsoid = %.0f   (the rest: costs, stores, next query point)'
+          % (np.median(raw[:, 0, 4]) / H, np.median(raw[:, 0, 5]) / H))

@@ -79,50 +79,67 @@ __device__ __forceinline__ double sym_lambda_max(double (&S)[NS][NS]) {
         // of a round's two rotations can only overlap in straight-line code): the arithmetic runs on whatever is there and
         // a select takes the identity; `live` says whether any rotation of the sweep was a real one.
         bool live = false;
-        auto angle = [&](int p, int q, double& c, double& sn) {
+        double tr = 0.0;     // sum of |diagonal| at the start of the sweep
+        auto angle = [&](int p, int q, double& c, double& sn, double& tn) {
             const double apq = S[p][q], app = S[p][p], aqq = S[q][q];
-            const bool on = fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * (fabs(app) + fabs(aqq));
+            // An off-diagonal entry below 1e-14 of the TRACE is left alone: all six together move no eigenvalue by more than
+            // 6e-14 of the trace (Weyl) -- lambda_max >= trace / n by 2.4e-13 of itself at worst, in practice by the entry's
+            // square over the gap.  (The first version compared with 1e-19 of the two diagonal entries involved: below what
+            // rounding leaves behind after every sweep, so no sweep ever came out clean and all eight always ran, most of
+            // them resolving the SMALL eigenvalues of an elongated ellipsoid, which lambda_max does not need.)
+            const bool on = fabs(apq) > 1e-300 && fabs(apq) > 1e-14 * tr;
             const double a = aqq - app, b = 2.0 * apq;
             const double t = (a < 0.0 ? -b : b) / (fabs(a) + sqrt(fma(a, a, b * b)));
             const double cc = rsqrt(fma(t, t, 1.0));
             c = on ? cc : 1.0;
             sn = on ? t * cc : 0.0;
+            tn = on ? t : 0.0;
             live = live || on;
         };
-        auto rotate = [&](int p, int q, double c, double sn) {
+        // S <- J^T S J for the rotation J in the (p, q) plane, as the symmetric update it is: the two rows / columns outside
+        // the plane (2 entries each for n = 4), the two diagonal entries (a_pp - t a_pq, a_qq + t a_pq) and a_pq = 0 -- a
+        // dozen operations where the two-sided product is 64; on one wave per SIMD every f64 operation is ~6 cycles of issue.
+        auto rotate = [&](int p, int q, double c, double sn, double tn) {
             const bool on = sn != 0.0;      // (a skipped rotation leaves every entry as it is, a NaN neighbour included)
+            const double apq = S[p][q];
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {  // columns p, q
+            for (int k = 0; k < NS; ++k) {
+                if (k == p || k == q) continue;
                 const double skp = S[k][p], skq = S[k][q];
-                S[k][p] = on ? c * skp - sn * skq : skp;
-                S[k][q] = on ? sn * skp + c * skq : skq;
+                const double np_ = on ? c * skp - sn * skq : skp;
+                const double nq_ = on ? sn * skp + c * skq : skq;
+                S[k][p] = np_;
+                S[p][k] = np_;
+                S[k][q] = nq_;
+                S[q][k] = nq_;
             }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {  // rows p, q
-                const double spk = S[p][k], sqk = S[q][k];
-                S[p][k] = on ? c * spk - sn * sqk : spk;
-                S[q][k] = on ? sn * spk + c * sqk : sqk;
-            }
+            S[p][p] = on ? S[p][p] - tn * apq : S[p][p];
+            S[q][q] = on ? S[q][q] + tn * apq : S[q][q];
+            S[p][q] = on ? 0.0 : apq;
+            S[q][p] = S[p][q];
         };
         for (int sweep = 0; sweep < 8; ++sweep) {
+            tr = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) tr += fabs(S[i][i]);
             if constexpr (NS == 4) {
                 constexpr int kRound[3][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {0, 3, 1, 2}};
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    double c0, s0, c1, s1;
-                    angle(kRound[r][0], kRound[r][1], c0, s0);
-                    angle(kRound[r][2], kRound[r][3], c1, s1);
-                    rotate(kRound[r][0], kRound[r][1], c0, s0);
-                    rotate(kRound[r][2], kRound[r][3], c1, s1);
+                    double c0, s0, t0, c1, s1, t1;
+                    angle(kRound[r][0], kRound[r][1], c0, s0, t0);
+                    angle(kRound[r][2], kRound[r][3], c1, s1, t1);
+                    rotate(kRound[r][0], kRound[r][1], c0, s0, t0);
+                    rotate(kRound[r][2], kRound[r][3], c1, s1, t1);
                 }
             } else {
 #pragma unroll
                 for (int p = 0; p < NS - 1; ++p)
 #pragma unroll
                     for (int q = p + 1; q < NS; ++q) {
-                        double c, sn;
-                        angle(p, q, c, sn);
-                        rotate(p, q, c, sn);
+                        double c, sn, tn;
+                        angle(p, q, c, sn, tn);
+                        rotate(p, q, c, sn, tn);
                     }
             }
             if (!live) break;       // a sweep without a real rotation: converged (every later sweep would do nothing either)

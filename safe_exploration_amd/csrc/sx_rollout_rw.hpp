@@ -46,6 +46,9 @@
 #ifndef SX_RW_PF
 #define SX_RW_PF 2         // Kstar fragment pairs in flight ahead of the MFMAs that consume them (3 spills at n_pad = 208)
 #endif
+#ifndef SX_RW_RCLOCAL
+#define SX_RW_RCLOCAL 0    // n_s >= 3: finish() copies the reachability constants from LDS to registers in one batch (measured: no gain, 5 spilled dwords at <4,1,6>)
+#endif
 #ifndef SX_RW_POLYFOLD
 #define SX_RW_POLYFOLD 0   // the cubic in w = r / u with the unit folded into its coefficients (one VALU instruction less per value)
 #endif
@@ -647,6 +650,15 @@ void cem_rollout_rw_kernel(GpConst<NS, NS + NU> gc, ReachConst<NS, NU> rc, CostC
                 rw_collect<NS, D, NRB, true>(fc, lds, tid, z, mean, var, jac);
 #ifdef SX_STAMPS
                 const unsigned long long f1 = stamp();
+#endif
+#if SX_RW_RCLOCAL
+                if constexpr (NS >= 3) {
+                    // the reachability constants (~60 doubles at n_s = 4) in ONE batch of LDS reads at the head of the chain:
+                    // left in LDS, each is requested where it is used, an exposed round trip of ~130 cycles every time
+                    const ReachConst<NS, NU> rloc = frc;
+                    SX_PIN();
+                    reach_ellipsoid<NS, NU>(rloc, p, Q, u, mean, var, jac, p1, Q1, st_step);
+                } else
 #endif
                 reach_ellipsoid<NS, NU>(frc, p, Q, u, mean, var, jac, p1, Q1, st_step);
 #ifdef SX_STAMPS
